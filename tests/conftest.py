@@ -1,0 +1,59 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+PRETRAINED = ["swap2", "softcorridor", "swap12", "swarm50", "singlequad"]
+SYNTHETIC = ["synth_nTh3_midcross4", "synth_nTh4_softcorridor", "synth_nTh3_swarm"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """one tests/golden/<name>.npz: reference inputs + reference outputs."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.meta = json.loads(str(self.z["meta"]))
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def t(self, k, **kw):
+        return torch.from_numpy(np.array(self.z[k])).to(**kw)
+
+    def state_dict(self):
+        return {k[3:]: torch.from_numpy(self.z[k]) for k in self.z.files if k.startswith("sd/")}
+
+    def has(self, k):
+        return k in self.z.files
+
+
+_cache = {}
+
+
+def load_golden(name):
+    if name not in _cache:
+        _cache[name] = Golden(name)
+    return _cache[name]
+
+
+@pytest.fixture(params=PRETRAINED + SYNTHETIC)
+def golden(request):
+    return load_golden(request.param)
+
+
+@pytest.fixture(params=PRETRAINED)
+def golden_pretrained(request):
+    return load_golden(request.param)
