@@ -1,0 +1,150 @@
+/*
+ * nocf.h -- C ABI of libnocf.so: the MI355X (gfx950) OCflow rollout hot path.
+ *
+ * The reference (donken/NeuralOC) is pure Python and has no FFI; this header is the
+ * boundary a maintainer binds with ctypes (stub in INTEGRATION.md).  Each entry point
+ * names the reference interface it replaces (file:line into donken/NeuralOC).
+ *
+ * Conventions
+ *   - every pointer marked "device" is a HIP device pointer on the current device;
+ *     all tensors are dense row-major fp32 unless stated otherwise
+ *   - functions enqueue work on `stream` (a hipStream_t passed as void*, 0 = default
+ *     stream) and return without synchronising; nothing is allocated or freed
+ *   - return value: 0 ok; <0 argument error (NOCF_E_*); >0 a hipError_t
+ *   - no exceptions, no aborts, no global mutable state
+ */
+#ifndef NOCF_H
+#define NOCF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NOCF_VERSION 100            /* major*100 + minor */
+
+#define NOCF_E_NULL      (-1)       /* required pointer is NULL                     */
+#define NOCF_E_SHAPE     (-2)       /* d/m/nTh/n/nt out of the supported range      */
+#define NOCF_E_PROB      (-3)       /* unknown problem kind / obstacle combination  */
+#define NOCF_E_WORKSPACE (-4)       /* workspace too small (see nocf_workspace_bytes) */
+#define NOCF_E_STEPPER   (-5)       /* stepper is neither NOCF_RK4 nor NOCF_RK1     */
+#define NOCF_E_LDS       (-6)       /* network too deep/wide for the 160 KiB LDS plan */
+
+/* stepper, src/OCflow.py:46-49 ("rk4" / "rk1") */
+#define NOCF_RK4 4
+#define NOCF_RK1 1
+
+/* problem classes, src/problem/{Cross2D,SwarmTraj,Quadcopter}.py */
+#define NOCF_PROB_CROSS2D    0
+#define NOCF_PROB_SWARMTRAJ  1
+#define NOCF_PROB_QUADCOPTER 2
+
+/* obstacle strings of the problem constructors */
+#define NOCF_OBS_NONE         0
+#define NOCF_OBS_SOFTCORRIDOR 1    /* Cross2D.py:43-48   */
+#define NOCF_OBS_HARDCORRIDOR 2    /* Cross2D.py:49-52   */
+#define NOCF_OBS_BLOCKS       3    /* SwarmTraj.py:46-50 */
+
+/* The value network Phi (src/Phi.py:57-87).  Pointers are the tensors of the reference
+ * state_dict, unmodified: N.layers.0.weight, N.layers.0.bias, N.layers.{1..nTh-1}.weight
+ * stacked, ...bias stacked, w.weight, A, c.weight; cb = c.bias[0]. */
+typedef struct NocfPhi {
+    int32_t d;          /* space dimension; inputs are (x,t) in R^{d+1}              */
+    int32_t m;          /* hidden width                                               */
+    int32_t nTh;        /* number of ResNet layers, >= 2 (src/Phi.py:25-27)           */
+    int32_t r;          /* rows of A = min(10, d+1) (src/Phi.py:75)                   */
+    const float* K0;    /* device [m, d+1]                                            */
+    const float* b0;    /* device [m]                                                 */
+    const float* K;     /* device [nTh-1, m, m]                                       */
+    const float* b;     /* device [nTh-1, m]                                          */
+    const float* w;     /* device [m]                                                 */
+    const float* A;     /* device [r, d+1]                                            */
+    const float* cw;    /* device [d+1]                                               */
+    float cb;
+} NocfPhi;
+
+/* One problem object (the attributes the reference's calcLHQW/calcGradpH/calcCtrls read). */
+typedef struct NocfProb {
+    int32_t kind;       /* NOCF_PROB_*                                                */
+    int32_t obstacle;   /* NOCF_OBS_*                                                 */
+    int32_t n_agents;   /* d / agentDim                                               */
+    int32_t training;   /* prob.training: masks and thresholds differ */
+    /* Python-side floats are doubles; the kernels derive their fp32 constants from these the
+     * way torch does when a Python scalar meets an fp32 tensor (thresholds such as 3.2*r or
+     * 2.0+r are formed in double, then rounded once). */
+    double r;           /* agent radius                                               */
+    double alph_Q;
+    double alph_W;
+    double mass;        /* Quadcopter only                                            */
+    double grav;        /* Quadcopter only                                            */
+    const float* xtarget; /* device [d]                                               */
+} NocfProb;
+
+int nocf_version(void);
+
+/* bytes of scratch `workspace` a call with these shapes needs (packed weight images) */
+size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh);
+
+/* number of control components per sample: d (Cross2D, SwarmTraj) or 4*n_agents (Quadcopter) */
+int nocf_ctrl_dim(const NocfProb* prob, int32_t d);
+
+/*
+ * OCflow -- replaces src/OCflow.py:7-95 (driver), :104-140 (ocOdefun), :143-184 (steppers)
+ * together with Phi.getGrad (src/Phi.py:99-138), Phi.forward (:91-96) and the problem's
+ * calcLHQW / calcGradpH / calcCtrls for every stage, fused into one launch.
+ *
+ *   x          device [n, d]          initial states (not modified)
+ *   t0,t1,nt   tspan and number of steps; h=(t1-t0)/nt, times advance in double like the reference
+ *   alph       host  [6]              only [0],[3],[4],[5] are used (SURVEY 8a note 7)
+ *   z_out      device [n, d+4]        final z = [x(T) | L | HJt | Q | W]           (nullable)
+ *   persample  device [n, 7]          per-sample [L, G, HJt, HJfin, HJgrad, Q, W] = the
+ *                                     reference's noMean=True list, src/OCflow.py:66-76 (nullable)
+ *   cost_sums  device [8]             sums over the n samples of the 7 columns above, then n.
+ *                                     Deterministic (fixed-order, fp64-accumulated) reduction.
+ *                                     The caller forms means / Jc (and all-reduces first when
+ *                                     the batch is sharded over GPUs).                (nullable)
+ *   zFull      device [nt+1, n, d+4]  intermediates=True: z after every step, slot 0 = z0.
+ *                                     TIME-MAJOR; the reference's [n, d+4, nt+1] is the
+ *                                     permute(1,2,0) view of it.                       (nullable)
+ *   ctrlFull   device [nt+1, n, a]    controls, a = nocf_ctrl_dim(); slot 0 stays zero and slot
+ *                                     k+1 uses (z_{k+1}, t_k) exactly like src/OCflow.py:51-55.
+ *                                     Required iff zFull is given.
+ */
+int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob,
+                     const float* x, int64_t n,
+                     double t0, double t1, int32_t nt, int32_t stepper,
+                     const float* alph,
+                     float* z_out, float* persample, float* cost_sums,
+                     float* zFull, float* ctrlFull,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Phi.getGrad -- replaces src/Phi.py:99-138.  s: device [n, d+1] -> grad: device [n, d+1] */
+int nocf_phi_grad_f32(const NocfPhi* phi, const float* s, int64_t n, float* grad,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Phi.forward -- replaces src/Phi.py:91-96.  s: device [n, d+1] -> value: device [n] */
+int nocf_phi_forward_f32(const NocfPhi* phi, const float* s, int64_t n, float* value,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Problem physics on given (x, p) -- replaces calcLHQW / calcGradpH / calcCtrls of
+ * src/problem/Cross2D.py:69-165, SwarmTraj.py:68-167, Quadcopter.py:65-174.
+ *   x, p     device [n, d]
+ *   lhqw     device [n, 4]   columns L, H, Q, W   (Q as the reference returns it: scaled by
+ *                            alph_Q for Cross2D, un-scaled for SwarmTraj/Quadcopter)  (nullable)
+ *   gradpH   device [n, d]                                                          (nullable)
+ *   ctrls    device [n, a]                                                          (nullable)
+ */
+int nocf_prob_eval_f32(const NocfProb* prob, int32_t d, const float* x, const float* p, int64_t n,
+                       float* lhqw, float* gradpH, float* ctrls, void* stream);
+
+/* layout probe used by the tests: D = sum_k A_k B_k through the same 4x4x1 MFMA tile code
+ * the rollout uses.  a: device [4, K], b: device [K, 64] -> out: device [4, 64] */
+int nocf_selftest_mfma(const float* a, const float* b, int32_t K, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOCF_H */

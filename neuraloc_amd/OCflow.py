@@ -1,0 +1,97 @@
+"""OCflow -- drop-in for src/OCflow.py:7-95 on an MI355X.
+
+Same call signature and return values as the reference:
+
+    Jc, cs = OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[...], intermediates=False, noMean=False)
+
+but the whole rollout (nt RK steps x stages, each: grad Phi + problem physics + running
+costs, then the terminal costs) is one HIP launch (nocf_rollout_f32).  This module only
+marshals arguments and forms the 7 means / Jc from the 8 sums the kernel returns.
+There is no CPU or eager-torch fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_STEPPERS = {"rk4": _lib.NOCF_RK4, "rk1": _lib.NOCF_RK1}
+
+
+def ocG(z, xtarget):
+    """terminal residual z[:, :d] - xtarget (src/OCflow.py:97-101)"""
+    d = xtarget.shape[0]
+    return z[:, 0:d] - xtarget
+
+
+def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
+    """run the HIP rollout; returns (persample [n,7], sums [8], zFull_tm, ctrlFull_tm)"""
+    x = _lib.require_device_f32(x, "x")
+    if x.dim() != 2:
+        raise ValueError("x must be nex-by-d")
+    n, d = x.shape
+    if d != Phi.d:
+        raise ValueError(f"x has d={d} but Phi was built for d={Phi.d}")
+    if int(nt) < 1:
+        # the reference divides by zero here (src/OCflow.py:25); SURVEY 8a note 10
+        raise ValueError("nt must be >= 1")
+    if stepper not in _STEPPERS:
+        # the reference silently integrates nothing for an unknown stepper (src/OCflow.py:46-49)
+        raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
+    if len(alph) < 6:
+        raise ValueError("alph needs 6 entries")
+    Phi._guard_no_autograd(x, "OCflow")
+    phi_st, keep1, ws = Phi._c_struct()
+    prob_st, keep2 = prob._c_struct(x.device)
+    dev = x.device
+    persample = torch.empty(n, 7, dtype=torch.float32, device=dev)
+    sums = torch.empty(8, dtype=torch.float32, device=dev)
+    zFull = ctrlFull = None
+    if intermediates:
+        cdim = _lib.lib().nocf_ctrl_dim(C.byref(prob_st), d)
+        zFull = torch.empty(nt + 1, n, d + 4, dtype=torch.float32, device=dev)
+        ctrlFull = torch.empty(nt + 1, n, cdim, dtype=torch.float32, device=dev)
+    alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+    with torch.cuda.device(dev):
+        rc = _lib.lib().nocf_rollout_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+                                         float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
+                                         None, _lib.ptr(persample), _lib.ptr(sums),
+                                         _lib.ptr(zFull), _lib.ptr(ctrlFull),
+                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "nocf_rollout_f32")
+    return persample, sums, zFull, ctrlFull
+
+
+def costs_from_sums(sums, alph):
+    """means of the 7 cost terms and Jc from the kernel's 8 sums (7 column sums + count).
+    cs order is [L, G, HJt, HJfin, HJgrad, Q, W]; G is un-weighted (src/OCflow.py:80-90)."""
+    means = sums[:7] / sums[7]
+    cs = [means[i] for i in range(7)]
+    Jc = cs[0] + alph[0] * cs[1] + alph[3] * cs[2] + alph[4] * cs[3] + alph[5] * cs[4]
+    return Jc, cs
+
+
+def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0],
+           intermediates=False, noMean=False):
+    """
+    :param x:       nex-by-d tensor on the MI355X, fp32
+    :param Phi:     neuraloc_amd.Phi
+    :param prob:    neuraloc_amd problem object (Cross2D / SwarmTraj / Quadcopter)
+    :param tspan:   [t0, t1]
+    :param nt:      number of time steps
+    :param stepper: "rk4" or "rk1"
+    :param alph:    6 multipliers [G, Q, W, HJt, HJfin, HJgrad]; entries 0,3,4,5 are used here
+    :param intermediates: return (zFull [nex,d+4,nt+1], ctrlFull [nex,a,nt+1]) instead
+    :param noMean:  return per-sample nex-by-1 costs instead of means (wins over intermediates,
+                    like the reference: src/OCflow.py:66-76)
+    :return: (Jc, cs)  or  (zFull, ctrlFull)
+    """
+    persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates and not noMean)
+    if noMean:
+        cs = [persample[:, i:i + 1] for i in range(7)]
+        Jc = cs[0] + alph[0] * cs[1] + alph[3] * cs[2] + alph[4] * cs[3] + alph[5] * cs[4]
+        return Jc, cs
+    if intermediates:
+        # kernel layout is time-major [nt+1, nex, .]; the reference's is [nex, ., nt+1]
+        return zF.permute(1, 2, 0), cF.permute(1, 2, 0)
+    return costs_from_sums(sums, alph)

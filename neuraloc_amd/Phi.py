@@ -1,0 +1,130 @@
+"""Host-side mirror of the reference's value network interface (src/Phi.py).
+
+`Phi(nTh, m, d, r=10, alph=[1.0]*6)` keeps the reference constructor, attribute names and
+state_dict keys (A, c.weight, c.bias, w.weight, N.layers.{i}.weight/.bias), so checkpoints
+and NeuralOC-style drivers work unchanged.  The arithmetic does not live here: `forward`
+and `getGrad` hand the parameter tensors to the HIP library (nocf_phi_forward_f32 /
+nocf_phi_grad_f32).  No torch fallback exists -- CPU tensors raise.
+"""
+import copy
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def antiderivTanh(x):
+    """activation of the ResNet: |x| + log(1+exp(-2|x|)) (src/Phi.py:8-9).  Plain elementwise
+    helper kept for API compatibility; the rollout evaluates it inside the HIP kernels."""
+    ax = x.abs()
+    return ax + torch.log(1 + torch.exp(-2.0 * ax))
+
+
+def derivTanh(x):
+    """1 - tanh^2 (src/Phi.py:12-13; unused upstream, kept for the import surface)."""
+    return 1 - torch.tanh(x) ** 2
+
+
+class ResNN(nn.Module):
+    """Parameter container of the ResNet body N (src/Phi.py:16-38): one (d+1)->m opening
+    layer and nTh-1 m->m residual layers, step hN = 1/(nTh-1)."""
+
+    def __init__(self, d, m, nTh=2):
+        super().__init__()
+        if nTh < 2:
+            # the reference prints and exit(1)s (src/Phi.py:25-27); a library raises instead
+            raise ValueError("nTh must be an integer >= 2")
+        self.d, self.m, self.nTh = d, m, nTh
+        first = nn.Linear(d + 1, m, bias=True)
+        second = nn.Linear(m, m, bias=True)
+        self.layers = nn.ModuleList([first, second] + [copy.deepcopy(second) for _ in range(nTh - 2)])
+        self.act = antiderivTanh
+        self.h = 1.0 / (self.nTh - 1)
+
+    def forward(self, x):
+        raise NotImplementedError("ResNN is evaluated inside the fused HIP kernels; call Phi(x) / Phi.getGrad(x)")
+
+
+class Phi(nn.Module):
+    """Phi(x,t) = w' N([x;t]) + 1/2 [x;t]' A'A [x;t] + c'[x;t] + c_b   (src/Phi.py:56-138)."""
+
+    def __init__(self, nTh, m, d, r=10, alph=[1.0] * 6):
+        super().__init__()
+        self.m, self.nTh, self.d, self.alph = m, nTh, d, alph
+        r = min(r, d + 1)
+        # same construction order as the reference so a seeded init draws the same numbers
+        self.A = nn.Parameter(torch.zeros(r, d + 1), requires_grad=True)
+        self.A = nn.init.xavier_uniform_(self.A)
+        self.c = nn.Linear(d + 1, 1, bias=True)
+        self.w = nn.Linear(m, 1, bias=False)
+        self.N = ResNN(d, m, nTh=nTh)
+        self.w.weight.data = torch.ones(self.w.weight.data.shape)
+        self.c.weight.data = torch.zeros(self.c.weight.data.shape)
+        self.c.bias.data = torch.zeros(self.c.bias.data.shape)
+        self._ws = None
+
+    # ---- boundary helpers -------------------------------------------------------------
+    def _c_struct(self):
+        """(NocfPhi, keep-alive list, workspace tensor) for the current parameters."""
+        dev = self.A.device
+        lay = self.N.layers
+        keep = []
+
+        def dv(t, name):
+            t = _lib.require_device_f32(t.detach(), name)
+            keep.append(t)
+            return t.data_ptr()
+
+        if self.nTh == 2:
+            Kst, bst = lay[1].weight, lay[1].bias
+        else:
+            Kst = torch.stack([lay[i].weight.detach() for i in range(1, self.nTh)])
+            bst = torch.stack([lay[i].bias.detach() for i in range(1, self.nTh)])
+        st = _lib.NocfPhi()
+        st.d, st.m, st.nTh, st.r = self.d, self.m, self.nTh, self.A.shape[0]
+        st.K0 = dv(lay[0].weight, "N.layers.0.weight")
+        st.b0 = dv(lay[0].bias, "N.layers.0.bias")
+        st.K = dv(Kst, "N.layers[1:].weight")
+        st.b = dv(bst, "N.layers[1:].bias")
+        st.w = dv(self.w.weight, "w.weight")
+        st.A = dv(self.A, "A")
+        st.cw = dv(self.c.weight, "c.weight")
+        st.cb = float(self.c.bias.detach().cpu().item())
+        nbytes = _lib.lib().nocf_workspace_bytes(self.d, self.m, self.nTh)
+        if nbytes == 0:
+            raise RuntimeError("nocf_workspace_bytes: unsupported (d, m, nTh)")
+        if self._ws is None or self._ws.device != dev or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return st, keep, self._ws
+
+    def _guard_no_autograd(self, x, what):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                f"{what}: differentiating through the HIP path (trainOC's Jc.backward()) is the next scope row "
+                "(SURVEY.md section 8f); call under torch.no_grad()")
+
+    def forward(self, x):
+        """Phi(s), n-by-1 (src/Phi.py:91-96)."""
+        x = _lib.require_device_f32(x, "x")
+        self._guard_no_autograd(x, "Phi.forward")
+        st, keep, ws = self._c_struct()
+        out = torch.empty(x.shape[0], 1, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().nocf_phi_forward_f32(C.byref(st), _lib.ptr(x), x.shape[0], _lib.ptr(out),
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+        _lib.check(rc, "nocf_phi_forward_f32")
+        return out
+
+    def getGrad(self, x):
+        """analytic gradient of Phi wrt (x,t), n-by-(d+1) (src/Phi.py:99-138)."""
+        x = _lib.require_device_f32(x, "x")
+        self._guard_no_autograd(x, "Phi.getGrad")
+        st, keep, ws = self._c_struct()
+        out = torch.empty(x.shape[0], self.d + 1, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().nocf_phi_grad_f32(C.byref(st), _lib.ptr(x), x.shape[0], _lib.ptr(out),
+                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+        _lib.check(rc, "nocf_phi_grad_f32")
+        return out

@@ -1,0 +1,94 @@
+"""ctypes binding of libnocf.so (include/nocf.h).  There is NO fallback: if the HIP library
+is missing or a call fails, the product path raises."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnocf.so")
+
+NOCF_RK4, NOCF_RK1 = 4, 1
+PROB_CROSS2D, PROB_SWARMTRAJ, PROB_QUADCOPTER = 0, 1, 2
+OBS_CODES = {None: 0, "softcorridor": 1, "hardcorridor": 2, "blocks": 3}
+
+_ERRORS = {-1: "NOCF_E_NULL (required pointer is NULL)", -2: "NOCF_E_SHAPE (d/m/nTh/n/nt unsupported)",
+           -3: "NOCF_E_PROB (unknown problem kind / obstacle)", -4: "NOCF_E_WORKSPACE (workspace too small)",
+           -5: "NOCF_E_STEPPER", -6: "NOCF_E_LDS (network does not fit the LDS plan)"}
+
+fp = C.POINTER(C.c_float)
+
+
+class NocfPhi(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("nTh", C.c_int32), ("r", C.c_int32),
+                ("K0", C.c_void_p), ("b0", C.c_void_p), ("K", C.c_void_p), ("b", C.c_void_p),
+                ("w", C.c_void_p), ("A", C.c_void_p), ("cw", C.c_void_p), ("cb", C.c_float)]
+
+
+class NocfProb(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("obstacle", C.c_int32), ("n_agents", C.c_int32), ("training", C.c_int32),
+                ("r", C.c_double), ("alph_Q", C.c_double), ("alph_W", C.c_double),
+                ("mass", C.c_double), ("grav", C.c_double), ("xtarget", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """the loaded library; raises RuntimeError when it was not built (python __graft_entry__.py)"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"neuraloc_amd: HIP library {LIB_PATH} is missing. Build it with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                           "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.nocf_version.restype = C.c_int
+    L.nocf_workspace_bytes.restype = C.c_size_t
+    L.nocf_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.nocf_ctrl_dim.restype = C.c_int
+    L.nocf_ctrl_dim.argtypes = [C.POINTER(NocfProb), C.c_int32]
+    L.nocf_rollout_f32.restype = C.c_int
+    L.nocf_rollout_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_void_p, C.c_int64,
+                                   C.c_double, C.c_double, C.c_int32, C.c_int32, fp,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]
+    for name in ("nocf_phi_grad_f32", "nocf_phi_forward_f32"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(NocfPhi), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.nocf_prob_eval_f32.restype = C.c_int
+    L.nocf_prob_eval_f32.argtypes = [C.POINTER(NocfProb), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.nocf_selftest_mfma.restype = C.c_int
+    L.nocf_selftest_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {_ERRORS.get(rc, rc)}")
+    raise RuntimeError(f"{what}: HIP error {rc}")
+
+
+def require_device_f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the OCflow hot path runs only on an MI355X (ROCm 'cuda' device); "
+                           "there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} has dtype {t.dtype}: the HIP path computes in fp32 only")
+    return t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

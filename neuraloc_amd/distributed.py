@@ -1,0 +1,40 @@
+"""Batch-sharded OCflow: one process per GPU, samples split by rows, one all-reduce.
+
+Samples are independent until the final mean (src/OCflow.py:80-86), so each rank integrates
+its contiguous slice of x and contributes 8 numbers (7 cost sums + its row count); a single
+SUM all-reduce over RCCL/xGMI (backend "nccl" on ROCm) makes the means identical on all
+ranks.  No other collective exists on this path.
+"""
+import torch
+import torch.distributed as dist
+
+from .OCflow import _launch, costs_from_sums
+
+
+def shard_rows(n, rank, world):
+    """contiguous, balanced row range [lo, hi) of rank `rank` among `world` ranks"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def reduce_cost_sums(local_sums, group=None):
+    """SUM all-reduce of the 8-vector [7 cost sums, count]; in place, returns it"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_sums, op=dist.ReduceOp.SUM, group=group)
+    return local_sums
+
+
+def OCflow_sharded(x_local, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0] * 6, group=None, local_rollout=None):
+    """OCflow over a batch whose rows are spread over the ranks of `group`.
+
+    x_local is this rank's slice.  Returns the same (Jc, cs) on every rank, equal (up to the
+    summation order of 8 fp32 numbers) to OCflow on the concatenated batch.
+    `local_rollout` exists for the CPU/gloo tests, which inject a checker for the per-rank sums;
+    the product path always uses the HIP launch."""
+    if local_rollout is None:
+        _, sums, _, _ = _launch(x_local, Phi, prob, tspan, nt, stepper, alph, False)
+    else:
+        sums = local_rollout(x_local)
+    sums = reduce_cost_sums(sums, group)
+    return costs_from_sums(sums, alph)

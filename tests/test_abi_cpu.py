@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/nocf.h declares;
+argument errors come back as codes (no compute call needs a GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import __graft_entry__ as entry
+from neuraloc_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    entry.build()
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported(L):
+    hdr = open(os.path.join(REPO, "include", "nocf.h")).read()
+    names = set(re.findall(r"\b(nocf_[a-z0-9_]+)\s*\(", hdr))
+    assert {"nocf_rollout_f32", "nocf_phi_grad_f32", "nocf_phi_forward_f32", "nocf_prob_eval_f32",
+            "nocf_version", "nocf_workspace_bytes", "nocf_ctrl_dim", "nocf_selftest_mfma"} <= names
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in nocf.h but not exported"
+    assert L.nocf_version() == 100
+
+
+def test_workspace_sizes(L):
+    # swarm50: 9*40*64 + 3*136*64 + 2*8*128*64 float4 images + padded vectors
+    n4 = 9 * 40 * 64 + 3 * 136 * 64 + 2 * 8 * 128 * 64
+    nv = 9 * 64 + 8 * 64 + 8 * 64 + 3 * 64
+    assert L.nocf_workspace_bytes(150, 512, 2) == (n4 * 4 + nv) * 4
+    assert L.nocf_workspace_bytes(4, 32, 2) > 0
+    assert L.nocf_workspace_bytes(4, 32, 1) == 0          # nTh < 2 is rejected (src/Phi.py:25-27)
+
+
+def test_argument_errors_are_codes(L):
+    assert L.nocf_rollout_f32(None, None, None, 1, 0.0, 1.0, 1, 4, None, None, None, None, None, None, None, 0, None) == -1
+    pb = _lib.NocfProb()
+    pb.kind, pb.n_agents = 2, 3
+    assert L.nocf_ctrl_dim(C.byref(pb), 36) == 12
+    pb.kind = 0
+    assert L.nocf_ctrl_dim(C.byref(pb), 36) == 36
+
+
+def test_product_path_refuses_cpu_tensors():
+    import neuraloc_amd as na
+    net = na.Phi(2, 8, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.getGrad(torch.zeros(2, 5))
+    prob = na.Cross2D(torch.zeros(4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        na.OCflow(torch.zeros(2, 4), net, prob, [0.0, 1.0], 4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "neuraloc_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_state_dict_contract():
+    import neuraloc_amd as na
+    net = na.Phi(3, 8, 4)
+    assert list(net.state_dict().keys()) == ["A", "c.weight", "c.bias", "w.weight", "N.layers.0.weight",
+                                             "N.layers.0.bias", "N.layers.1.weight", "N.layers.1.bias",
+                                             "N.layers.2.weight", "N.layers.2.bias"]
+    assert net.A.shape == (5, 5) and float(net.w.weight.min()) == 1.0 and float(net.c.weight.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        na.Phi(1, 8, 4)

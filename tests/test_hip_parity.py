@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path, called through the package (ctypes -> C ABI), against
+ (a) the reference's own outputs stored in tests/golden/*.npz and
+ (b) the oracle on the same inputs.
+
+Stated fp32 tolerances (the reference's own fp32-vs-fp64 noise floor is
+1e-6 relative on states and up to 1.6e-3 on near-zero per-sample costs):
+   states / trajectories : |diff| <= 1e-4 + 1e-5 |ref|
+   batch means (Jc, cs)  : rel 1e-4 (abs 1e-6 for tiny terms)
+   per-sample costs      : rel 1e-3 + abs 1e-3, isolated mask-flip outliers counted and bounded
+"""
+import numpy as np
+import pytest
+import torch
+
+import neuraloc_amd as na
+from neuraloc_amd import _lib
+from oracle import ocflow_oracle as orc
+from util_hip import count_off, full_states, make_net, make_oracle, make_prob
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def mean_close(got, want, name=""):
+    got, want = float(got), float(want)
+    assert abs(got - want) <= 1e-4 * abs(want) + 1e-6, f"{name}: hip {got:.8e} vs ref {want:.8e}"
+
+
+def test_mfma_tile_layout():
+    """the 4x4x1 MFMA tile code computes out[4,64] = a[4,K] @ b[K,64] (asymmetric data)"""
+    K = 37
+    a = torch.arange(4 * K, dtype=torch.float32).reshape(4, K) * 0.25 - 3.0
+    b = (torch.arange(K * 64, dtype=torch.float32).reshape(K, 64) % 13) - 6.0 + 0.5 * (torch.arange(64) % 3)
+    ad, bd = a.to(DEV), b.to(DEV)
+    out = torch.empty(4, 64, device=DEV)
+    rc = _lib.lib().nocf_selftest_mfma(_lib.ptr(ad), _lib.ptr(bd), K, _lib.ptr(out), _lib.stream_ptr(DEV))
+    _lib.check(rc, "selftest")
+    torch.cuda.synchronize()
+    want = a.double() @ b.double()
+    assert (out.cpu().double() - want).abs().max().item() <= 1e-3 * want.abs().max().item() * 1e-3 + 1e-2
+
+
+def test_phi_value_and_gradient(golden):
+    g = golden
+    net = make_net(g, DEV)
+    s = g.t("unit/s")
+    with torch.no_grad():
+        val = net(s.to(DEV)).cpu()
+        grad = net.getGrad(s.to(DEV)).cpu()
+    assert val.shape == (s.shape[0], 1) and grad.shape == s.shape
+    for got, key in ((val, "unit/phi"), (grad, "unit/gradphi")):
+        want = torch.from_numpy(g[key])
+        scale = want.abs().max().item()
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-5, f"{g.name} {key}: err {err:g} at scale {scale:g}"
+
+
+def test_phi_gradient_ragged_batch(golden_pretrained):
+    """batch sizes that are not a multiple of the 4-sample tile, including 1"""
+    g = golden_pretrained
+    net = make_net(g, DEV)
+    s = g.t("unit/s")
+    want = torch.from_numpy(g["unit/gradphi"])
+    with torch.no_grad():
+        for n in (1, 3, 5, 39):
+            got = net.getGrad(s[:n].to(DEV)).cpu()
+            assert (got - want[:n]).abs().max().item() <= 2e-5 * want.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_problem_physics(golden, mode):
+    g = golden
+    prob = make_prob(g, DEV, training=(mode == "train"))
+    x = g.t("unit/s")[:, :-1].contiguous().to(DEV)
+    p = g.t("unit/p").to(DEV)
+    L, H, Q, W = prob.calcLHQW(x, p)
+    got = torch.cat((L, H, Q, W), 1).cpu()
+    want = torch.from_numpy(g[f"unit/{mode}/LHQW"])
+    for j, nm in enumerate("LHQW"):
+        bad, worst = count_off(got[:, j], want[:, j], 1e-5, 1e-5 + 2e-4 * (nm in "LHW") * float(g.meta["alph_W"] > 0) *
+                               float(g.meta["n_agents"] > 2) * max(1.0, g.meta["alph_W"]))
+        assert bad == 0, f"{g.name} {mode} {nm}: {bad} off, worst {worst:g}"
+    gp = prob.calcGradpH(x, p).cpu()
+    ct = prob.calcCtrls(x, p).cpu()
+    for got2, key in ((gp, "gradpH"), (ct, "ctrls")):
+        want2 = torch.from_numpy(g[f"unit/{mode}/{key}"])
+        assert got2.shape == want2.shape
+        assert (got2 - want2).abs().max().item() <= 1e-5 * want2.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("tag", ["eval_rk4", "eval_rk1", "eval_seg", "train_rk4"])
+def test_rollout_against_reference_golden(golden, tag):
+    g = golden
+    if not g.has(tag + "/Jc"):
+        pytest.skip("case not in this fixture")
+    net = make_net(g, DEV)
+    prob = make_prob(g, DEV, training=tag.startswith("train"))
+    stepper = "rk1" if tag.endswith("rk1") else "rk4"
+    tspan = [float(v) for v in g[tag + "/tspan"]]
+    nt = int(g[tag + "/nt"])
+    alph = g.meta["alph"]
+    x = g.t("x").to(DEV)
+    with torch.no_grad():
+        Jc, cs = na.OCflow(x, net, prob, tspan, nt, stepper, alph)
+        Jn, csn = na.OCflow(x, net, prob, tspan, nt, stepper, alph, noMean=True)
+    want_cs = g[tag + "/cs"]
+    wtol = 1.0
+    mean_close(Jc, g[tag + "/Jc"], f"{g.name} {tag} Jc")
+    for j, nm in enumerate(["L", "G", "HJt", "HJfin", "HJgrad", "Q", "W"]):
+        mean_close(cs[j], want_cs[j], f"{g.name} {tag} {nm}")
+    tab = torch.cat(csn, 1).cpu()
+    assert tab.shape == (x.shape[0], 7) and Jn.shape == (x.shape[0], 1)
+    bad, worst = count_off(tab, g[tag + "/persample"], 1e-3, 1e-3)
+    assert bad <= 2, f"{g.name} {tag}: {bad} per-sample entries beyond rel 1e-3 + abs 1e-3 (worst {worst:g})"
+
+
+@pytest.mark.parametrize("tag", ["eval_rk4", "eval_seg", "train_rk4"])
+def test_intermediates_against_reference_golden(golden, tag):
+    g = golden
+    if not g.has(tag + "/zFull"):
+        pytest.skip("case not in this fixture")
+    net = make_net(g, DEV)
+    prob = make_prob(g, DEV, training=tag.startswith("train"))
+    tspan = [float(v) for v in g[tag + "/tspan"]]
+    nt = int(g[tag + "/nt"])
+    zw = torch.from_numpy(g[tag + "/zFull"])
+    cw = torch.from_numpy(g[tag + "/ctrlFull"])
+    n, d = zw.shape[0], g.meta["d"]
+    with torch.no_grad():
+        zF, cF = na.OCflow(g.t("x")[:n].to(DEV), net, prob, tspan, nt, "rk4", g.meta["alph"], intermediates=True)
+    zF, cF = zF.cpu(), cF.cpu()
+    assert zF.shape == zw.shape and cF.shape == cw.shape
+    bad, worst = count_off(zF[:, :d], zw[:, :d], 1e-5, 1e-4)
+    assert bad == 0, f"{g.name} {tag}: {bad} state entries off (worst {worst:g})"
+    bad, worst = count_off(zF[:, d:], zw[:, d:], 1e-3, 1e-3)
+    assert bad <= 4, f"{g.name} {tag}: {bad} running-cost entries off (worst {worst:g})"
+    bad, worst = count_off(cF, cw, 1e-4, 1e-3)
+    assert bad == 0, f"{g.name} {tag}: {bad} control entries off (worst {worst:g})"
+    assert float(cF[:, :, 0].abs().max()) == 0.0
+
+
+def test_full_size_against_reference_and_oracle(golden_pretrained):
+    """BASELINE.json sizes: Jc/cs against the reference's stored result and the oracle's per-sample table"""
+    g = golden_pretrained
+    m = g.meta
+    net = make_net(g, DEV)
+    prob = make_prob(g, DEV, training=False)
+    x = full_states(g, int(g["full/seed"]))
+    with torch.no_grad():
+        Jc, cs = na.OCflow(x.to(DEV), net, prob, [0.0, 1.0], m["nt"], "rk4", m["alph"])
+        _, csn = na.OCflow(x.to(DEV), net, prob, [0.0, 1.0], m["nt"], "rk4", m["alph"], noMean=True)
+    mean_close(Jc, g["full/Jc"], f"{g.name} full Jc")
+    for j in range(7):
+        mean_close(cs[j], g["full/cs"][j], f"{g.name} full cs[{j}]")
+    P, S = make_oracle(g, training=False)
+    with torch.no_grad():
+        want = orc.persample_table(x, P, S, [0.0, 1.0], m["nt"], "rk4", m["alph"])
+    bad, worst = count_off(torch.cat(csn, 1), want, 1e-3, 1e-3)
+    assert bad <= max(2, x.shape[0] // 500), f"{g.name}: {bad} per-sample entries off (worst {worst:g})"
+
+
+def test_rk4_is_fourth_order(golden_pretrained):
+    """size-independent property: halving h shrinks the state error ~16x (checked loosely, vs nt=4x)"""
+    g = golden_pretrained
+    if g.name in ("swap2",):
+        pytest.skip("hard-corridor masks make the flow non-smooth")
+    net = make_net(g, DEV)
+    prob = make_prob(g, DEV, training=False)
+    x = g.t("x")[:8].to(DEV)
+    d = g.meta["d"]
+
+    def final_state(nt):
+        with torch.no_grad():
+            zF, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", g.meta["alph"], intermediates=True)
+        return zF[:, :d, -1].double().cpu()
+
+    ref = final_state(64)
+    e1 = (final_state(4) - ref).abs().max().item()
+    e2 = (final_state(8) - ref).abs().max().item()
+    assert e2 < e1 / 6.0 or e1 < 1e-4, f"{g.name}: errors {e1:g} -> {e2:g}"
+
+
+def test_shard_invariance_and_determinism(golden_pretrained):
+    """splitting the batch changes nothing per sample; repeated calls are bitwise identical"""
+    g = golden_pretrained
+    net = make_net(g, DEV)
+    prob = make_prob(g, DEV, training=False)
+    x = g.t("x").to(DEV)
+    nt, alph = min(10, g.meta["nt"]), g.meta["alph"]
+    with torch.no_grad():
+        _, a = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph, noMean=True)
+        _, b = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph, noMean=True)
+        _, lo = na.OCflow(x[:17], net, prob, [0.0, 1.0], nt, "rk4", alph, noMean=True)
+        _, hi = na.OCflow(x[17:], net, prob, [0.0, 1.0], nt, "rk4", alph, noMean=True)
+    a, b = torch.cat(a, 1), torch.cat(b, 1)
+    assert torch.equal(a, b)
+    assert torch.equal(a, torch.cat((torch.cat(lo, 1), torch.cat(hi, 1)), 0))
+
+
+def test_error_behaviour():
+    g_net = na.Phi(2, 8, 4).to(DEV)
+    prob = na.Cross2D(torch.zeros(4, device=DEV))
+    x = torch.zeros(3, 4, device=DEV)
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            na.OCflow(x, g_net, prob, [0.0, 1.0], 0)
+        with pytest.raises(ValueError):
+            na.OCflow(x, g_net, prob, [0.0, 1.0], 4, stepper="rk2")
+    with pytest.raises(NotImplementedError):
+        na.OCflow(x, g_net, prob, [0.0, 1.0], 4)           # autograd through the rollout: next scope row
+    x0 = x.clone()
+    with torch.no_grad():
+        na.OCflow(x, g_net, prob, [0.0, 1.0], 2)
+    assert torch.equal(x, x0)                              # inputs are never mutated

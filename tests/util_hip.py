@@ -1,0 +1,61 @@
+"""helpers for the GPU parity tests: build package objects / oracle records from a golden fixture"""
+import torch
+
+import neuraloc_amd as na
+from oracle import ocflow_oracle as orc
+
+CLS = {"Cross2D": na.Cross2D, "SwarmTraj": na.SwarmTraj, "Quadcopter": na.Quadcopter}
+KIND = {"Cross2D": orc.KIND_CROSS2D, "SwarmTraj": orc.KIND_SWARM, "Quadcopter": orc.KIND_QUAD}
+
+
+def make_net(g, dev):
+    m = g.meta
+    net = na.Phi(nTh=m["nTh"], m=m["m"], d=m["d"], alph=m["alph"])
+    net.load_state_dict(g.state_dict())
+    return net.to(dev).eval()
+
+
+def make_prob(g, dev, training):
+    m = g.meta
+    xt = g.t("xtarget").to(dev)
+    if m["prob_class"] == "Quadcopter":
+        prob = na.Quadcopter(xt, obstacle=None, alph_Q=m["alph_Q"], alph_W=m["alph_W"])
+    else:
+        prob = CLS[m["prob_class"]](xt, obstacle=m["obstacle"], alph_Q=m["alph_Q"], alph_W=m["alph_W"], r=m["r"])
+    prob.train() if training else prob.eval()
+    return prob
+
+
+def make_oracle(g, training):
+    m = g.meta
+    P = orc.PhiParams.from_state_dict(g.state_dict())
+    S = orc.ProbSpec(kind=KIND[m["prob_class"]], xtarget=g.t("xtarget"), obstacle=m["obstacle"],
+                     alph_Q=m["alph_Q"], alph_W=m["alph_W"], r=m["r"], training=training)
+    return P, S
+
+
+def closed_form_normal(n, d, seed):
+    """same table as tests/golden/make_golden.py (Box-Muller over Weyl sequences)"""
+    import numpy as np
+    i = np.arange(n * d, dtype=np.float64) + 1.0 + 1000.0 * seed
+    u1 = np.clip(np.mod(i * 0.6180339887498949, 1.0), 1e-9, 1.0)
+    u2 = np.mod(i * 0.7548776662466927 + 0.31, 1.0)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return torch.from_numpy(z.reshape(n, d).astype(np.float32))
+
+
+def full_states(g, seed):
+    """the BASELINE-size batch make_golden.py used for its full/* entries"""
+    m = g.meta
+    xInit = g.t("xInit")
+    xi = closed_form_normal(m["n_full"], m["d"], seed)
+    if m["name"] == "singlequad":
+        xi[:, 3:] = 0.0
+    x = xInit + m["var0"] * xi
+    x[0] = xInit[0]
+    return x.contiguous()
+
+
+def count_off(got, want, rtol, atol):
+    got, want = got.double().cpu(), torch.as_tensor(want).double()
+    return int(((got - want).abs() > atol + rtol * want.abs()).sum()), float((got - want).abs().max())
