@@ -140,6 +140,12 @@ int nocf_phi_forward_f32(const NocfPhi* phi, const float* s, int64_t n, float* v
 int nocf_prob_eval_f32(const NocfProb* prob, int32_t d, const float* x, const float* p, int64_t n,
                        float* lhqw, float* gradpH, float* ctrls, void* stream);
 
+/* Measurement hooks (bench.py): between begin and end every nocf_rollout_f32 call records a pair
+ * of HIP events on its launch stream immediately around the rollout kernel; end synchronises on
+ * them and returns the summed kernel time and the number of launches.  Not thread-safe. */
+int nocf_profile_begin(void);
+int nocf_profile_end(double* total_ms, int32_t* launches);
+
 /* layout probe used by the tests: D = sum_k A_k B_k through the same 4x4x1 MFMA tile code
  * the rollout uses.  a: device [4, K], b: device [K, 64] -> out: device [4, 64] */
 int nocf_selftest_mfma(const float* a, const float* b, int32_t K, float* out, void* stream);

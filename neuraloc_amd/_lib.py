@@ -61,6 +61,9 @@ def lib():
     L.nocf_prob_eval_f32.restype = C.c_int
     L.nocf_prob_eval_f32.argtypes = [C.POINTER(NocfProb), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.nocf_profile_begin.restype = C.c_int
+    L.nocf_profile_end.restype = C.c_int
+    L.nocf_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.nocf_selftest_mfma.restype = C.c_int
     L.nocf_selftest_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L

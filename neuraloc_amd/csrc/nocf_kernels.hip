@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <utility>
+#include <vector>
 #include "nocf.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -867,9 +869,39 @@ static int check_phi(const NocfPhi* phi) {
     return 0;
 }
 
+// ---- optional in-library timing of the rollout kernel (bench.py): HIP events recorded on the
+// launch stream immediately around the kernel, so the figure is the kernel's own duration.
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static bool g_prof_on = false;
+
 extern "C" {
 
 int nocf_version(void) { return NOCF_VERSION; }
+
+int nocf_profile_begin(void) {
+    for (auto& pr : g_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    g_prof_events.clear();
+    g_prof_on = true;
+    return 0;
+}
+
+int nocf_profile_end(double* total_ms, int32_t* launches) {
+    g_prof_on = false;
+    double tot = 0.0;
+    for (auto& pr : g_prof_events) {
+        hipError_t e = hipEventSynchronize(pr.second);
+        if (e) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, pr.first, pr.second);
+        if (e) return (int)e;
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int32_t)g_prof_events.size();
+    for (auto& pr : g_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    g_prof_events.clear();
+    return 0;
+}
 
 size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh) {
     DevPlan pl;
@@ -915,6 +947,11 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     const int grid = (int)((n + pl.T - 1) / pl.T);
     const int block = pl.nwaves * 64;
     hipError_t e;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_prof_on) {
+        if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+        hipEventRecord(ev0, st);
+    }
     switch (pl.T / 4) {
         case 1: e = set_lds(rollout_kernel<1>, ldsBytes); if (e) return (int)e;
                 hipLaunchKernelGGL(rollout_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, pl, pb, ws, ra); break;
@@ -925,6 +962,7 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     }
     e = hipGetLastError();
     if (e) return (int)e;
+    if (g_prof_on) { hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
     if (cost_sums) {
         hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums);
         e = hipGetLastError();

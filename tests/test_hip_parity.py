@@ -103,15 +103,35 @@ def test_rollout_against_reference_golden(golden, tag):
     with torch.no_grad():
         Jc, cs = na.OCflow(x, net, prob, tspan, nt, stepper, alph)
         Jn, csn = na.OCflow(x, net, prob, tspan, nt, stepper, alph, noMean=True)
-    want_cs = g[tag + "/cs"]
-    wtol = 1.0
-    mean_close(Jc, g[tag + "/Jc"], f"{g.name} {tag} Jc")
-    for j, nm in enumerate(["L", "G", "HJt", "HJfin", "HJgrad", "Q", "W"]):
-        mean_close(cs[j], want_cs[j], f"{g.name} {tag} {nm}")
     tab = torch.cat(csn, 1).cpu()
     assert tab.shape == (x.shape[0], 7) and Jn.shape == (x.shape[0], 1)
-    bad, worst = count_off(tab, g[tag + "/persample"], 1e-3, 1e-3)
-    assert bad <= 2, f"{g.name} {tag}: {bad} per-sample entries beyond rel 1e-3 + abs 1e-3 (worst {worst:g})"
+    want = torch.from_numpy(g[tag + "/persample"])
+    # Per-sample costs: rel 1e-3 + abs 1e-3.  Q/W/L are discontinuous in x (masks), so a sample that
+    # sits within fp32 noise of a threshold may flip -- the reference's own fp32 run flips one swarm50
+    # train-mode sample against its fp64 run (rel 7e-3 on that sample, 1.9e-4 on the batch mean).
+    # Such rows are counted, bounded and reported, and the batch means are compared without them.
+    off = (tab.double() - want.double()).abs() > 1e-3 + 1e-3 * want.double().abs()
+    flipped = off.any(dim=1)
+    nflip = int(flipped.sum())
+    assert nflip <= 2, f"{g.name} {tag}: {nflip} samples beyond rel 1e-3 + abs 1e-3: rows {flipped.nonzero().flatten().tolist()}"
+    names = ["L", "G", "HJt", "HJfin", "HJgrad", "Q", "W"]
+    if nflip == 0:
+        mean_close(Jc, g[tag + "/Jc"], f"{g.name} {tag} Jc")
+        for j, nm in enumerate(names):
+            mean_close(cs[j], g[tag + "/cs"][j], f"{g.name} {tag} {nm}")
+    else:
+        print(f"[mask-flip] {g.name} {tag}: rows {flipped.nonzero().flatten().tolist()} excluded from the mean check")
+        keep = ~flipped
+        for j, nm in enumerate(names):
+            mean_close(tab[keep, j].double().mean(), want[keep, j].double().mean(), f"{g.name} {tag} {nm} (unflipped rows)")
+    # the reported means / Jc are exactly the means of the per-sample table (deterministic fp64 reduction)
+    for j, nm in enumerate(names):
+        assert abs(float(cs[j]) - tab[:, j].double().mean().item()) <= 2e-6 * abs(float(cs[j])) + 1e-9
+    Jtab = (tab[:, 0].double().mean() + alph[0] * tab[:, 1].double().mean() + alph[3] * tab[:, 2].double().mean()
+            + alph[4] * tab[:, 3].double().mean() + alph[5] * tab[:, 4].double().mean()).item()
+    assert abs(float(Jc) - Jtab) <= 2e-6 * abs(Jtab)
+    assert (Jn.cpu() - (tab[:, 0:1] + alph[0] * tab[:, 1:2] + alph[3] * tab[:, 2:3] + alph[4] * tab[:, 3:4]
+                        + alph[5] * tab[:, 4:5])).abs().max().item() <= 1e-5 * Jn.abs().max().item()
 
 
 @pytest.mark.parametrize("tag", ["eval_rk4", "eval_seg", "train_rk4"])
@@ -160,7 +180,7 @@ def test_full_size_against_reference_and_oracle(golden_pretrained):
 
 
 def test_rk4_is_fourth_order(golden_pretrained):
-    """size-independent property: halving h shrinks the state error ~16x (checked loosely, vs nt=4x)"""
+    """size-independent property: halving h shrinks the final-state error ~16x (asserted: >= 8x)"""
     g = golden_pretrained
     if g.name in ("swap2",):
         pytest.skip("hard-corridor masks make the flow non-smooth")
@@ -174,10 +194,11 @@ def test_rk4_is_fourth_order(golden_pretrained):
             zF, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", g.meta["alph"], intermediates=True)
         return zF[:, :d, -1].double().cpu()
 
-    ref = final_state(64)
-    e1 = (final_state(4) - ref).abs().max().item()
-    e2 = (final_state(8) - ref).abs().max().item()
-    assert e2 < e1 / 6.0 or e1 < 1e-4, f"{g.name}: errors {e1:g} -> {e2:g}"
+    # fp64 oracle errors vs nt=320 (measured): nt=16 -> 1.6e-3..0.43, nt=32 -> 8e-5..6e-3 (ratio >= 20)
+    ref = final_state(128)
+    e1 = (final_state(16) - ref).abs().max().item()
+    e2 = (final_state(32) - ref).abs().max().item()
+    assert e2 < e1 / 8.0 or e1 < 1e-3, f"{g.name}: errors {e1:g} -> {e2:g}"
 
 
 def test_shard_invariance_and_determinism(golden_pretrained):
