@@ -146,6 +146,10 @@ int nocf_prob_eval_f32(const NocfProb* prob, int32_t d, const float* x, const fl
 int nocf_profile_begin(void);
 int nocf_profile_end(double* total_ms, int32_t* launches);
 
+/* Diagnostic builds (-DNOCF_STAMPS, libnocf_stamps.so) only: device buffer of 12 uint64 per
+ * workgroup receiving per-phase shader-cycle totals.  The production library returns an error. */
+int nocf_debug_set_stamp_buffer(void* device_buf);
+
 /* layout probe used by the tests: D = sum_k A_k B_k through the same 4x4x1 MFMA tile code
  * the rollout uses.  a: device [4, K], b: device [K, 64] -> out: device [4, 64] */
 int nocf_selftest_mfma(const float* a, const float* b, int32_t K, float* out, void* stream);

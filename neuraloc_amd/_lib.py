@@ -6,7 +6,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnocf.so")
+# NOCF_LIB_PATH: diagnostics only (e.g. the -DNOCF_STAMPS build); the default is the in-tree production library
+LIB_PATH = os.environ.get("NOCF_LIB_PATH") or os.path.join(_HERE, "csrc", "libnocf.so")
 
 NOCF_RK4, NOCF_RK1 = 4, 1
 PROB_CROSS2D, PROB_SWARMTRAJ, PROB_QUADCOPTER = 0, 1, 2
@@ -64,6 +65,8 @@ def lib():
     L.nocf_profile_begin.restype = C.c_int
     L.nocf_profile_end.restype = C.c_int
     L.nocf_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.nocf_debug_set_stamp_buffer.restype = C.c_int
+    L.nocf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     L.nocf_selftest_mfma.restype = C.c_int
     L.nocf_selftest_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L

@@ -14,7 +14,9 @@
 //
 // Weights are re-laid out once per call (pack_kernel) into lane-linear float4 images so a
 // wave's weight fetch is one fully coalesced 1 KiB global_load_dwordx4 per 4 k-steps; the
-// images (<= 2.9 MB for swarm50) live in the XCD L2s for the whole rollout.
+// images (2.7 MB for swarm50) stay in the XCD L2s for the whole rollout.  Each wave streams its
+// column block through a 16-deep register ring (up to 16 KiB in flight per wave): at 4..8 samples
+// per workgroup the stream is bound by L2->CU bandwidth/latency, not by the MFMA pipe.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -26,29 +28,39 @@
 #include "nocf.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define UN 8                 // k-quads (4 k-steps each) per software-pipelined chunk
-#define MAX_SK 4             // max split-K factor of a GEMM phase
+// All LDS lives in one dynamic array that every device function names directly (never through a
+// stored pointer), so each access is a ds_* instruction, not a flat one.
+extern __shared__ __attribute__((aligned(16))) float lds[];
+
+#ifndef NOCF_MAXTHREADS
+#define NOCF_MAXTHREADS 512   // waves per workgroup * 64; 256 gives each wave the whole 512-register file
+#endif
+#define HALF 8               // k-quads (4 k-steps each) per third of the weight ring
+#define MAX_SK 8             // max split-K factor of a GEMM phase
 #define MAX_NTH 12
+#define ZQLD 16              // row stride of the z = A s rows (r <= 16)
 
 // ------------------------------------------------------------------------------------------
 // plan: shapes, packed-image offsets, LDS carve.  Built on the host, passed by value.
 // ------------------------------------------------------------------------------------------
 struct DevPlan {
-    int d, D1, m, r, ME, nTh;
-    int MB, MBE, DB;                 // 64-column blocks: hidden, hidden+A rows, d+1
-    int KQ1, KQ6, KQm;               // k-quads of the three GEMM shapes, padded to UN
-    int SK1, SK6, SKm;               // split-K factors
-    int LD, LDs, PLD, GLD;           // LDS row strides (floats)
+    int d, D1, m, r, nTh;
+    int MB, DB;                      // 64-column blocks: hidden width, d+1
+    int KQ1, KQm;                    // k-quads of the two contraction lengths (d+1, m), padded to 2*HALF
+    int SK1, SK6, SKm;               // split-K factors of the opening / closing / residual GEMMs
+    int LD, LDs, GLD, ZLD;           // LDS row strides (floats)
     int T, nwaves;
     long oW0f, oW0b, oWf, oWb, strideW;   // float4 offsets of the images in the workspace
-    long ob0, ob, ow, ocw;                // float offsets of the padded vectors
+    long ob0, ob, ow, ocw, oA, oPlan;     // float offsets of the padded vectors, the copy of A, the plan copy
     float hN, cb;
     // LDS carve (float offsets)
-    int lSB, lU0, lU1, lTH, lAV, lV, lPART, lG, lZ0, lZA, lDZ, lRED, lSC, lPHI, lTRIG;
-    int ZLD;
+    int lSB, lU0, lU1, lTH, lAV, lV0, lV1, lPART, lG, lZQ, lZ0, lZA, lDZ, lRED, lSC, lPHI, lTRIG, lPT;
     int ldsFloats;
 };
+
+static_assert(sizeof(DevPlan) % 4 == 0 && sizeof(DevPlan) / 4 <= 256, "plan copy is done by one 256-thread block");
 
 struct DevProb {
     int kind, obstacle, nAgents, training, agentDim;
@@ -61,20 +73,12 @@ struct DevPhi {
 };
 
 // ------------------------------------------------------------------------------------------
-// weight packing
+// weight packing: image[cb][kq][lane] = float4 of B[k = 4kq..4kq+3][col = 64cb + lane]
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float k0ext(const DevPhi& P, int m, int r, int D1, int j, int k) {
-    // rows 0..m-1 = K0, rows m..m+r-1 = A  (the low-rank quadratic rides along the opening layer)
-    if (k >= D1) return 0.f;
-    if (j < m) return P.K0[(long)j * D1 + k];
-    if (j < m + r) return P.A[(long)(j - m) * D1 + k];
-    return 0.f;
-}
-
 __global__ void pack_kernel(DevPlan pl, DevPhi P, float* __restrict__ ws) {
     float4* ws4 = reinterpret_cast<float4*>(ws);
-    const long nW0f = (long)pl.MBE * pl.KQ1 * 64;
-    const long nW0b = (long)pl.DB * pl.KQ6 * 64;
+    const long nW0f = (long)pl.MB * pl.KQ1 * 64;       // opening:  B[k][j] = K0[j][k]
+    const long nW0b = (long)pl.DB * pl.KQm * 64;       // closing:  B[k][i] = K0[k][i]
     const long nWl = (long)pl.MB * pl.KQm * 64;
     const long nLayers = pl.nTh - 1;
     const long total4 = nW0f + nW0b + 2 * nLayers * nWl;
@@ -82,32 +86,41 @@ __global__ void pack_kernel(DevPlan pl, DevPhi P, float* __restrict__ ws) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += stride) {
         float v[4];
         long dst;
-        if (idx < nW0f) {                               // GEMM1 image: B[k][j] = K0ext[j][k]
+        if (idx < nW0f) {
             long q = idx;
-            int lane = q & 63; q >>= 6;
-            int kq = q % pl.KQ1; int cb = q / pl.KQ1;
-            for (int e = 0; e < 4; ++e) v[e] = k0ext(P, pl.m, pl.r, pl.D1, cb * 64 + lane, kq * 4 + e);
+            const int lane = q & 63; q >>= 6;
+            const int kq = q % pl.KQ1, cb = q / pl.KQ1;
+            const int j = cb * 64 + lane;
+            for (int e = 0; e < 4; ++e) {
+                const int k = kq * 4 + e;
+                v[e] = (j < pl.m && k < pl.D1) ? P.K0[(long)j * pl.D1 + k] : 0.f;
+            }
             dst = pl.oW0f + idx;
-        } else if (idx < nW0f + nW0b) {                 // GEMM6 image: B[k][i] = K0ext[k][i]
+        } else if (idx < nW0f + nW0b) {
             long q = idx - nW0f;
-            int lane = q & 63; q >>= 6;
-            int kq = q % pl.KQ6; int cb = q / pl.KQ6;
-            for (int e = 0; e < 4; ++e) v[e] = k0ext(P, pl.m, pl.r, pl.D1, kq * 4 + e, cb * 64 + lane);
+            const int lane = q & 63; q >>= 6;
+            const int kq = q % pl.KQm, cb = q / pl.KQm;
+            const int i = cb * 64 + lane;
+            for (int e = 0; e < 4; ++e) {
+                const int k = kq * 4 + e;
+                v[e] = (k < pl.m && i < pl.D1) ? P.K0[(long)k * pl.D1 + i] : 0.f;
+            }
             dst = pl.oW0b + (idx - nW0f);
         } else {
-            long q = idx - nW0f - nW0b;
-            int layer = q / (2 * nWl);                  // 0 -> reference layer 1
+            const long q = idx - nW0f - nW0b;
+            const int layer = q / (2 * nWl);             // 0 -> reference layer 1
             long w = q - (long)layer * 2 * nWl;
-            int back = w >= nWl;
+            const int back = w >= nWl;
             if (back) w -= nWl;
-            int lane = w & 63; long ww = w >> 6;
-            int kq = ww % pl.KQm; int cb = ww / pl.KQm;
+            const int lane = w & 63; const long ww = w >> 6;
+            const int kq = ww % pl.KQm, cb = ww / pl.KQm;
             const float* Kl = P.K + (long)layer * pl.m * pl.m;
+            const int a = cb * 64 + lane;
             for (int e = 0; e < 4; ++e) {
-                int a = cb * 64 + lane, k = kq * 4 + e;
+                const int k = kq * 4 + e;
                 float val = 0.f;
-                if (a < pl.m && k < pl.m) val = back ? Kl[(long)k * pl.m + a]   // B[j][k] = K[j][k]: (jq*4+e, col)
-                                                     : Kl[(long)a * pl.m + k];  // B[k][j] = K[j][k]
+                if (a < pl.m && k < pl.m) val = back ? Kl[(long)k * pl.m + a]    // backward: B[j][col] = K[j][col]
+                                                     : Kl[(long)a * pl.m + k];   // forward:  B[k][j]   = K[j][k]
                 v[e] = val;
             }
             dst = (back ? pl.oWb : pl.oWf) + (long)layer * pl.strideW + w;
@@ -115,19 +128,26 @@ __global__ void pack_kernel(DevPlan pl, DevPhi P, float* __restrict__ ws) {
         ws4[dst] = make_float4(v[0], v[1], v[2], v[3]);
     }
     // padded vectors
-    const long nb0 = (long)pl.MBE * 64, nb = nLayers * pl.MB * 64, nw = (long)pl.MB * 64, ncw = (long)pl.DB * 64;
+    const long nb0 = (long)pl.MB * 64, nb = nLayers * pl.MB * 64, nw = (long)pl.MB * 64, ncw = (long)pl.DB * 64;
     const long totalv = nb0 + nb + nw + ncw;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < totalv; idx += stride) {
         float val = 0.f;
         long dst;
         if (idx < nb0) { if (idx < pl.m) val = P.b0[idx]; dst = pl.ob0 + idx; }
         else if (idx < nb0 + nb) {
-            long q = idx - nb0; int layer = q / (pl.MB * 64); int c = q % (pl.MB * 64);
+            const long q = idx - nb0; const int layer = q / (pl.MB * 64); const int c = q % (pl.MB * 64);
             if (c < pl.m) val = P.b[(long)layer * pl.m + c];
             dst = pl.ob + q;
-        } else if (idx < nb0 + nb + nw) { long q = idx - nb0 - nb; if (q < pl.m) val = P.w[q]; dst = pl.ow + q; }
-        else { long q = idx - nb0 - nb - nw; if (q < pl.D1) val = P.cw[q]; dst = pl.ocw + q; }
+        } else if (idx < nb0 + nb + nw) { const long q = idx - nb0 - nb; if (q < pl.m) val = P.w[q]; dst = pl.ow + q; }
+        else { const long q = idx - nb0 - nb - nw; if (q < pl.D1) val = P.cw[q]; dst = pl.ocw + q; }
         ws[dst] = val;
+    }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)pl.r * pl.D1; idx += stride)
+        ws[pl.oA + idx] = P.A[idx];
+    // the plan itself, for the kernels that read it through a pointer
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevPlan) / 4) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&pl);
+        reinterpret_cast<unsigned*>(ws + pl.oPlan)[threadIdx.x] = src[threadIdx.x];
     }
 }
 
@@ -144,62 +164,83 @@ __device__ __forceinline__ float sigma_act(float o) {      // src/Phi.py:8-9
     return ao + logf(1.f + expf(-2.f * ao));
 }
 
+// sigma(o) and tanh(o) from one exponential: e = exp(-2|o|) in (0,1];
+//   sigma = |o| + log(1+e)           (the reference's own overflow-safe form, src/Phi.py:8-9)
+//   tanh  = sign(o) (1-e)/(1+e)      (absolute error <= ~1e-7, like any fp32 rounding of an O(1) value)
+// hardware v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp) instead of the ~60-instruction libm calls.
+__device__ __forceinline__ void act_pair(float o, float& sig, float& th) {
+    const float ao = fabsf(o);
+    const float e = __builtin_amdgcn_exp2f(ao * -2.885390081777927f);       // exp(-2|o|) = 2^(-2 log2(e) |o|)
+    const float p = 1.f + e;
+    sig = ao + 0.6931471805599453f * __builtin_amdgcn_logf(p);             // v_log_f32 is log2
+    th = copysignf((1.f - e) * __builtin_amdgcn_rcpf(p), o);
+}
+
+__device__ __forceinline__ float tanh_fast(float o) {
+    const float e = __builtin_amdgcn_exp2f(fabsf(o) * -2.885390081777927f);
+    return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), o);
+}
+
 struct Ctx {
-    float* lds;
     const float* ws;
+    __amdgpu_buffer_rsrc_t wrs;      // buffer descriptor over the packed workspace (wave-uniform)
     int tid, nthreads, wave, lane;
+#ifdef NOCF_STAMPS
+    mutable unsigned long long acc[12];
+    mutable unsigned long long last;
+#endif
 };
 
-// part[ks][t][col] = sum_{k in split ks} act[t][k] * B[k][col]
-template <int S>
-__device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, const float4* __restrict__ img,
-                                           int nblk, int KQ, int SK, const float* __restrict__ act, int ld) {
-    float* part = c.lds + pl.lPART;
-    const int pstride = pl.T * pl.PLD;
-    const int chunks = KQ / UN;
-    const int units = nblk * SK;
-    const int arow = c.lane & 3;
-    for (int u = c.wave; u < units; u += pl.nwaves) {
-        const int cb = u / SK, ks = u - cb * SK;
-        const int c0 = (chunks * ks) / SK, c1 = (chunks * (ks + 1)) / SK;
-        f32x4 acc[S][2];
+__device__ __forceinline__ void ctx_init(Ctx& c, const float* ws, unsigned ws_bytes) {
+    c.ws = ws;
+    c.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, ws_bytes, 0x00020000);
+    c.tid = threadIdx.x; c.nthreads = blockDim.x; c.lane = threadIdx.x & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform: scalar loop control
+#ifdef NOCF_STAMPS
+    for (int i = 0; i < 12; ++i) c.acc[i] = 0;
+    c.last = clock64();
+#endif
+}
+
+// one packed k-quad of weights for this lane: 16 B at (uniform byte offset soff) + lane*16
+__device__ __forceinline__ float4 wload(const Ctx& c, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.wrs, c.lane * 16, soff, 0);
+    float4 f;
+    f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+    return f;
+}
+
+// Diagnostic build only (-DNOCF_STAMPS): thread 0 of every workgroup accumulates the shader cycles
+// each phase takes (barrier waits included).  The production library contains no stamp.
+#ifdef NOCF_STAMPS
+#define STAMP(c, id) do { if ((c).tid == 0) { unsigned long long t_ = clock64(); (c).acc[id] += t_ - (c).last; (c).last = t_; } } while (0)
+#else
+#define STAMP(c, id) do { } while (0)
+#endif
+
+// One half of the weight ring: 8 k-quads = 32 k-steps = 32*S MFMAs.  Two register rings feed it:
+//   buf[8]  weights of this half; with RW each consumed entry is reloaded with the k-quad 16 further
+//           on (the ring's other half is in flight meanwhile: 8..16 KiB per wave outstanding)
+//   a[S][8] activations (LDS); with RA each consumed entry is reloaded with the k-quad 8 further on,
+//           so no MFMA waits on an LDS read it has just issued.
+// Weights come through buffer loads (scalar byte offset + lane*16: no per-load 64-bit address
+// arithmetic); no branch sits between the loads, so the waits are counted vmcnt/lgkmcnt.
+template <int S, bool RW, bool RA>
+__device__ __forceinline__ void ring_half(const Ctx& c, float4 (&buf)[HALF], float4 (&a)[S][HALF], f32x4 (&acc)[S][4],
+                                          int a_next /*float4 index*/, int ld /*floats*/, int w_next /*bytes*/) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) { acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[s][1] = acc[s][0]; }
-        const float4* wp = img + ((long)cb * KQ + (long)c0 * UN) * 64 + c.lane;
-        const float* ap = act + arow * ld + c0 * UN * 4;
-        float4 wc[UN], wn[UN];
-        if (c0 < c1) {
-#pragma unroll
-            for (int i = 0; i < UN; ++i) wc[i] = wp[i * 64];
-        }
-        for (int ch = c0; ch < c1; ++ch) {
-            wp += UN * 64;
-            if (ch + 1 < c1) {
-#pragma unroll
-                for (int i = 0; i < UN; ++i) wn[i] = wp[i * 64];
-            }
-#pragma unroll
-            for (int i = 0; i < UN; ++i) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float4 a = *reinterpret_cast<const float4*>(ap + s * 4 * ld + i * 4);
-                    acc[s][0] = mfma4(a.x, wc[i].x, acc[s][0]);
-                    acc[s][1] = mfma4(a.y, wc[i].y, acc[s][1]);
-                    acc[s][0] = mfma4(a.z, wc[i].z, acc[s][0]);
-                    acc[s][1] = mfma4(a.w, wc[i].w, acc[s][1]);
-                }
-            }
-            ap += UN * 4;
-#pragma unroll
-            for (int i = 0; i < UN; ++i) wc[i] = wn[i];
-        }
+    for (int i = 0; i < HALF; ++i) {
+        const float4 w = buf[i];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const f32x4 rsum = acc[s][0] + acc[s][1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                part[ks * pstride + (4 * s + q) * pl.PLD + cb * 64 + c.lane] = rsum[q];
+            const float4 av = a[s][i];
+            acc[s][0] = mfma4(av.x, w.x, acc[s][0]);
+            acc[s][1] = mfma4(av.y, w.y, acc[s][1]);
+            acc[s][2] = mfma4(av.z, w.z, acc[s][2]);
+            acc[s][3] = mfma4(av.w, w.w, acc[s][3]);
+            if (RA) a[s][i] = reinterpret_cast<const float4*>(lds)[a_next + s * ld + i];      // float4 index: ds_read_b128
         }
+        if (RW) buf[i] = wload(c, w_next + i * 1024);
     }
 }
 
@@ -209,34 +250,102 @@ __device__ __forceinline__ float part_sum(const float* part, int pstride, int SK
     return v;
 }
 
-// Segmented block reduction of NV values per thread.  Threads are split into T groups of
-// G = nthreads/T consecutive threads (group t serves sample t).  Result: out[t*NV + v].
-// Contains two barriers; every thread of the workgroup must call it.
+// out[t][col] = epi(t, col, sum_k act[t][k] * B[k][col]) for nblk 64-column blocks.
+//   img4     float4 offset of the packed image [nblk][KQ][64] in the workspace
+//   act_off  float offset in LDS of the activation rows [T][ld]
+// SK == 1: the wave that owns a column block applies epi straight from its accumulators.
+// SK  > 1: split-K partials go through LDS (fixed-order sum, deterministic); contains one barrier.
+// The caller puts a barrier after the call before anyone reads what epi wrote.
+template <int S, class Epi>
+__device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, long img4,
+                                           int nblk, int KQ, int SK, int act_off, int ld, Epi epi) {
+    const int partLD = nblk * 64;
+    const int pstride = pl.T * partLD;
+    const int pairs = KQ / (2 * HALF);             // K is padded to whole ring turns (2 halves)
+    const int units = nblk * SK;
+    const int arow = c.lane & 3;
+    for (int u = c.wave; u < units; u += pl.nwaves) {
+        const int cb = u / SK, ks = u - cb * SK;
+        const int p0 = (pairs * ks) / SK, p1 = (pairs * (ks + 1)) / SK;
+        const int np = p1 - p0;
+        f32x4 acc[S][4];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[s][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int wo = (int)((img4 + ((long)cb * KQ + (long)p0 * 2 * HALF) * 64) * 16);   // byte offset, wave-uniform
+        int ao = (act_off + arow * ld) / 4 + p0 * 2 * HALF;                         // float4 index, per lane (rows are 16-B aligned)
+        float4 A[HALF], B[HALF], av[S][HALF];
+        if (np > 0) {
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) A[i] = wload(c, wo + i * 1024);
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) B[i] = wload(c, wo + (HALF + i) * 1024);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) av[s][i] = reinterpret_cast<const float4*>(lds)[ao + s * ld + i];
+        }
+        for (int pr = 0; pr + 1 < np; ++pr) {
+            ring_half<S, true, true>(c, A, av, acc, ao + HALF, ld, wo + 2 * HALF * 1024);
+            ring_half<S, true, true>(c, B, av, acc, ao + 2 * HALF, ld, wo + 3 * HALF * 1024);
+            wo += 2 * HALF * 1024;
+            ao += 2 * HALF;
+        }
+        if (np > 0) {
+            ring_half<S, false, true>(c, A, av, acc, ao + HALF, ld, wo);
+            ring_half<S, false, false>(c, B, av, acc, ao, ld, wo);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const f32x4 rsum = (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
+            if (SK == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) epi(4 * s + q, cb * 64 + c.lane, rsum[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    lds[pl.lPART + ks * pstride + (4 * s + q) * partLD + cb * 64 + c.lane] = rsum[q];
+            }
+        }
+    }
+    if (SK > 1) {
+        __syncthreads();
+        for (int t = 0; t < pl.T; ++t)
+            for (int col = c.tid; col < partLD; col += c.nthreads)
+                epi(t, col, part_sum(lds + pl.lPART, pstride, SK, t * partLD + col));
+    }
+}
+
+// Segmented reduction of NV values per thread.  Threads are split into T groups of
+// G = nthreads/T consecutive threads (group t serves sample t).  After the call (it ends with a
+// barrier) group_total(...) gives any thread the total of sample t.
 template <int NV>
-__device__ __forceinline__ void group_reduce(const Ctx& c, const DevPlan& pl, float (&v)[NV], float* out) {
+__device__ __forceinline__ void group_reduce(const Ctx& c, const DevPlan& pl, float (&v)[NV]) {
     const int G = c.nthreads / pl.T;
     const int seg = G < 64 ? G : 64;
     for (int off = seg >> 1; off > 0; off >>= 1) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], off);
     }
-    float* red = c.lds + pl.lRED;
-    const int subseg = c.tid / seg;
+    float* red = lds + pl.lRED;
     if ((c.tid & (seg - 1)) == 0) {
+        const int subseg = c.tid / seg;
 #pragma unroll
         for (int i = 0; i < NV; ++i) red[subseg * NV + i] = v[i];
     }
     __syncthreads();
-    const int R = G / seg;                 // sub-segments per sample (>=1)
-    if (c.tid < pl.T * NV) {
-        const int t = c.tid / NV, i = c.tid - t * NV;
-        float s = red[(t * R) * NV + i];
-        for (int q = 1; q < R; ++q) s += red[(t * R + q) * NV + i];
-        out[t * NV + i] = s;
-    }
-    __syncthreads();
 }
 
+template <int NV>
+__device__ __forceinline__ float group_total(const Ctx& c, const DevPlan& pl, int t, int i) {
+    const int G = c.nthreads / pl.T;
+    const int R = G < 64 ? 1 : G / 64;          // sub-segments (waves) per sample
+    const float* red = lds + pl.lRED;
+    float s = red[(t * R) * NV + i];
+    for (int q = 1; q < R; ++q) s += red[(t * R + q) * NV + i];
+    return s;
+}
 
 // ------------------------------------------------------------------------------------------
 // grad Phi (and optionally Phi) for the T samples whose s=[x,t] rows sit in SB.
@@ -245,100 +354,118 @@ __device__ __forceinline__ void group_reduce(const Ctx& c, const DevPlan& pl, fl
 // ------------------------------------------------------------------------------------------
 template <int S>
 __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value) {
-    const float4* ws4 = reinterpret_cast<const float4*>(c.ws);
-    float* L = c.lds;
-    float* SB = L + pl.lSB;
-    float* U[2] = {L + pl.lU0, L + pl.lU1};
-    float* TH = L + pl.lTH;
-    float* AV = L + pl.lAV;
-    float* V = L + pl.lV;
-    float* PART = L + pl.lPART;
-    float* G = L + pl.lG;
-    const int T = pl.T, LD = pl.LD, PLD = pl.PLD, pstride = T * PLD;
+    const int T = pl.T, LD = pl.LD, m = pl.m, D1 = pl.D1, r = pl.r;
+    const int oSB = pl.lSB, oTH = pl.lTH, oAV = pl.lAV, oG = pl.lG, oZQ = pl.lZQ;
     const float hN = pl.hN;
     const float* b0 = c.ws + pl.ob0;
     const float* wv = c.ws + pl.ow;
     const float* cw = c.ws + pl.ocw;
+    const float* Araw = c.ws + pl.oA;
     const int lastLayer = pl.nTh - 1;
 
-    // ---- opening layer: o = s K0^T + b0 ; z = A s
     __syncthreads();
-    gemm_phase<S>(c, pl, ws4 + pl.oW0f, pl.MBE, pl.KQ1, pl.SK1, SB, pl.LDs);
-    __syncthreads();
-    for (int t = 0; t < T; ++t)
-        for (int col = c.tid; col < pl.ME; col += c.nthreads) {
-            const float raw = part_sum(PART, pstride, pl.SK1, t * PLD + col);
-            if (col < pl.m) {
-                const float o = raw + b0[col];
-                U[0][t * LD + col] = sigma_act(o);
-                TH[t * LD + col] = tanhf(o);
-            } else {
-                V[t * LD + col] = raw;                 // z = A s, consumed by the closing GEMM
+    STAMP(c, 10);
+    // ---- z = A s (the low-rank quadratic's inner product; A is at most 10 x (d+1)).  8 lanes share a row.
+    {
+        const int items = T * r * 8;
+        for (int base = 0; base < items; base += c.nthreads) {
+            const int id = base + c.tid;
+            const int part = id & 7, tr = id >> 3;
+            float acc = 0.f;
+            if (id < items) {
+                const int t = tr / r, rr = tr - t * r;
+                const float* arow = Araw + (long)rr * D1;
+                for (int i = part; i < D1; i += 8) acc += arow[i] * lds[oSB + t * pl.LDs + i];
             }
+            acc += __shfl_xor(acc, 4);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 1);
+            if (id < items && part == 0) { const int t = tr / r; lds[oZQ + t * ZQLD + (tr - t * r)] = acc; }
         }
+    }
+    // ---- opening layer: o = s K0^T + b0 ; u0 = sigma(o) ; gate0 = tanh(o)
+    gemm_phase<S>(c, pl, pl.oW0f, pl.MB, pl.KQ1, pl.SK1, oSB, pl.LDs, [&](int t, int col, float v) {
+        if (col < m) {
+            const float o = v + b0[col];
+            float sg, th;
+            act_pair(o, sg, th);
+            lds[pl.lU0 + t * LD + col] = sg;
+            lds[oTH + t * LD + col] = th;
+        }
+    });
+    __syncthreads();
+    STAMP(c, 0);
     int cur = 0;
     // ---- residual layers, forward
     for (int i = 1; i <= lastLayer; ++i) {
-        __syncthreads();
-        gemm_phase<S>(c, pl, ws4 + pl.oWf + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, U[cur], LD);
-        __syncthreads();
         const float* bi = c.ws + pl.ob + (long)(i - 1) * pl.MB * 64;
-        float* THi = TH + (long)i * T * LD;
-        for (int t = 0; t < T; ++t)
-            for (int col = c.tid; col < pl.m; col += c.nthreads) {
-                const float q = part_sum(PART, pstride, pl.SKm, t * PLD + col) + bi[col];
-                const float th = tanhf(q);
+        const int oTHi = oTH + i * T * LD;
+        const int oUc = cur ? pl.lU1 : pl.lU0, oUn = cur ? pl.lU0 : pl.lU1;
+        gemm_phase<S>(c, pl, pl.oWf + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, oUc, LD,
+                      [&](int t, int col, float v) {
+            if (col < m) {
+                const float q = v + bi[col];
                 if (i < lastLayer) {
-                    THi[t * LD + col] = th;
-                    U[cur ^ 1][t * LD + col] = U[cur][t * LD + col] + hN * sigma_act(q);
+                    float sg, th;
+                    act_pair(q, sg, th);
+                    lds[oTHi + t * LD + col] = th;
+                    lds[oUn + t * LD + col] = lds[oUc + t * LD + col] + hN * sg;
                 } else {
                     const float wj = wv[col];
-                    V[t * LD + col] = th * wj;
-                    AV[t * LD + col] = wj;
-                    if (need_value) U[cur ^ 1][t * LD + col] = U[cur][t * LD + col] + hN * sigma_act(q);
+                    lds[pl.lV0 + t * LD + col] = tanh_fast(q) * wj;
+                    lds[oAV + t * LD + col] = wj;
+                    if (need_value) lds[oUn + t * LD + col] = lds[oUc + t * LD + col] + hN * sigma_act(q);
                 }
             }
+        });
+        __syncthreads();
         cur ^= 1;
     }
+    STAMP(c, 2);
     // ---- Phi itself (final time only): w.u + 1/2 |A s|^2 + c.s + cb   (src/Phi.py:91-96)
     if (need_value) {
-        __syncthreads();
         const int Gsz = c.nthreads / T;
         const int t = c.tid / Gsz, j0 = c.tid - t * Gsz;
+        const int oU = cur ? pl.lU1 : pl.lU0;
         float acc[1] = {0.f};
-        for (int col = j0; col < pl.m; col += Gsz) acc[0] += wv[col] * U[cur][t * LD + col];
-        for (int q = pl.m + j0; q < pl.ME; q += Gsz) { const float z = V[t * LD + q]; acc[0] += 0.5f * z * z; }
-        for (int i = j0; i < pl.D1; i += Gsz) acc[0] += cw[i] * SB[t * pl.LDs + i];
-        group_reduce<1>(c, pl, acc, L + pl.lPHI);
-        if (c.tid < T) L[pl.lPHI + c.tid] += pl.cb;
+        for (int col = j0; col < m; col += Gsz) acc[0] += wv[col] * lds[oU + t * LD + col];
+        for (int q = j0; q < r; q += Gsz) { const float z = lds[oZQ + t * ZQLD + q]; acc[0] += 0.5f * z * z; }
+        for (int i = j0; i < D1; i += Gsz) acc[0] += cw[i] * lds[oSB + t * pl.LDs + i];
+        group_reduce<1>(c, pl, acc);
+        if (c.tid < T) lds[pl.lPHI + c.tid] = group_total<1>(c, pl, c.tid, 0) + pl.cb;
+        __syncthreads();
     }
     // ---- backward sweep: a <- a + hN K_i^T (tanh(.) . a)
+    int vb = 0;
     for (int i = lastLayer; i >= 1; --i) {
-        __syncthreads();
-        gemm_phase<S>(c, pl, ws4 + pl.oWb + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, V, LD);
-        __syncthreads();
-        const float* THp = TH + (long)(i - 1) * T * LD;
-        for (int t = 0; t < T; ++t)
-            for (int col = c.tid; col < pl.m; col += c.nthreads) {
-                const float a = AV[t * LD + col] + hN * part_sum(PART, pstride, pl.SKm, t * PLD + col);
-                AV[t * LD + col] = a;
-                V[t * LD + col] = THp[t * LD + col] * a;
+        const int oTHp = oTH + (i - 1) * T * LD;
+        const int oVc = vb ? pl.lV1 : pl.lV0, oVn = vb ? pl.lV0 : pl.lV1;
+        gemm_phase<S>(c, pl, pl.oWb + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, oVc, LD,
+                      [&](int t, int col, float v) {
+            if (col < m) {
+                const float a = lds[oAV + t * LD + col] + hN * v;
+                lds[oAV + t * LD + col] = a;
+                lds[oVn + t * LD + col] = lds[oTHp + t * LD + col] * a;
             }
+        });
+        __syncthreads();
+        vb ^= 1;
     }
+    STAMP(c, 4);
     // ---- closing: g = K0^T (tanh(o) . a) + A^T (A s) + c
+    gemm_phase<S>(c, pl, pl.oW0b, pl.DB, pl.KQm, pl.SK6, vb ? pl.lV1 : pl.lV0, LD, [&](int t, int i, float v) {
+        if (i < D1) {
+            float g = v + cw[i];
+            for (int q = 0; q < r; ++q) g += Araw[(long)q * D1 + i] * lds[oZQ + t * ZQLD + q];
+            lds[oG + t * pl.GLD + i] = g;
+        }
+    });
     __syncthreads();
-    gemm_phase<S>(c, pl, ws4 + pl.oW0b, pl.DB, pl.KQ6, pl.SK6, V, LD);
-    __syncthreads();
-    for (int t = 0; t < T; ++t)
-        for (int i = c.tid; i < pl.D1; i += c.nthreads)
-            G[t * pl.GLD + i] = part_sum(PART, pstride, pl.SK6, t * PLD + i) + cw[i];
-    __syncthreads();
+    STAMP(c, 6);
 }
 
 // ------------------------------------------------------------------------------------------
-// problem physics: (x = SB rows, p = G rows) -> DZ[t] = [-grad_p H | L | |dPhi/dt - H| | Q | W]
-// Cross2D.py:69-162, SwarmTraj.py:68-164, Quadcopter.py:65-113, utils.py:70-86.
-// LHQW[t*4..] receives (L,H,Q,W) as the reference's calcLHQW returns them.
+// problem physics.  Cross2D.py:69-162, SwarmTraj.py:68-164, Quadcopter.py:65-113, utils.py:70-86.
 // ------------------------------------------------------------------------------------------
 #define TWO_PI_D 6.283185307179586
 
@@ -391,13 +518,27 @@ __device__ __forceinline__ float obstacle_swarm(const DevProb& pb, float x0, flo
     return (in1 || in2) ? 1.f : 0.f;
 }
 
-// Every thread of the workgroup must call it.  want_ctrl: also leave the quadcopter thrust in SC.
-__device__ void physics_eval(const Ctx& c, const DevPlan& pl, const DevProb& pb, float* LHQW) {
-    float* Lm = c.lds;
+__device__ __forceinline__ bool want_W(const DevProb& pb) {
+    return (pb.kind == NOCF_PROB_QUADCOPTER) ? (pb.alphW > 0.0) : (pb.alphW != 0.0);
+}
+
+// pair table for the N>2 interaction sum: entry p = (i << 8) | j, i < j   (built once per launch)
+__device__ void build_pair_table(const Ctx& c, const DevPlan& pl, const DevProb& pb) {
+    if (pb.kind == NOCF_PROB_QUADCOPTER || pb.nAgents <= 2 || !want_W(pb)) return;
+    unsigned short* PT = reinterpret_cast<unsigned short*>(lds + pl.lPT);
+    const int N = pb.nAgents;
+    for (int idx = c.tid; idx < N * N; idx += c.nthreads) {
+        const int i = idx / N, j = idx - i * N;
+        if (i < j) PT[i * N - (i * (i + 1)) / 2 + (j - i - 1)] = (unsigned short)((i << 8) | j);
+    }
+}
+
+// Phase 1 (all threads): per-sample partial sums -> RED (ends with a barrier).
+//   v0 = sum p^2, v1 = raw obstacle sum, v2 = raw interaction sum; quadcopter: sin/cos table.
+__device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb) {
+    float* Lm = lds;
     const float* X = Lm + pl.lSB;
     const float* P = Lm + pl.lG;
-    float* DZ = Lm + pl.lDZ;
-    float* SC = Lm + pl.lSC;
     float* TRIG = Lm + pl.lTRIG;
     const int T = pl.T, d = pl.d, N = pb.nAgents, ad = pb.agentDim;
     const int Gsz = c.nthreads / T;
@@ -405,7 +546,7 @@ __device__ void physics_eval(const Ctx& c, const DevPlan& pl, const DevProb& pb,
     const float* x = X + t * pl.LDs;
     const float* p = P + t * pl.GLD;
 
-    float v[3] = {0.f, 0.f, 0.f};                  // sum p^2, raw obstacle sum, raw interaction sum
+    float v[3] = {0.f, 0.f, 0.f};
     for (int i = j0; i < d; i += Gsz) v[0] += p[i] * p[i];
     if (pb.kind == NOCF_PROB_CROSS2D) {
         if (pb.obstacle != NOCF_OBS_NONE)
@@ -414,8 +555,7 @@ __device__ void physics_eval(const Ctx& c, const DevPlan& pl, const DevProb& pb,
         if (pb.obstacle != NOCF_OBS_NONE && pb.alphQ > 0.0)
             for (int a = j0; a < N; a += Gsz) v[1] += obstacle_swarm(pb, x[3 * a], x[3 * a + 1], x[3 * a + 2]);
     }
-    const bool wantW = (pb.kind == NOCF_PROB_QUADCOPTER) ? (pb.alphW > 0.0) : (pb.alphW != 0.0);
-    if (wantW && N >= 2) {
+    if (want_W(pb) && N >= 2) {
         const float den = (float)(2.0 * pb.r * pb.r);
         const int pd = (pb.kind == NOCF_PROB_CROSS2D) ? 2 : 3;      // position components per agent
         if (N == 2) {
@@ -429,15 +569,30 @@ __device__ void physics_eval(const Ctx& c, const DevPlan& pl, const DevProb& pb,
         } else if (pb.kind != NOCF_PROB_QUADCOPTER) {
             const double fac = pb.training ? (pb.kind == NOCF_PROB_SWARMTRAJ ? 3.2 : 2.2) : 2.0;
             const float thr = (float)(fac * pb.r);
-            for (int idx = j0; idx < N * N; idx += Gsz) {
-                const int i = idx / N, j = idx - i * N;
-                if (i < j) {
-                    float s2 = 0.f;
-                    for (int k = 0; k < pd; ++k) { const float e = x[ad * i + k] - x[ad * j + k]; s2 += e * e; }
-                    const float dist = sqrtf(s2);
-                    if (dist < thr) {
-                        const float e = expf(-(dist * dist) / den);
-                        if (e != 1.f) v[2] += e;             // the reference drops entries equal to 1.
+            const float thr2 = thr * thr * 1.000002f;            // cheap reject; the exact test follows
+            const unsigned short* PT = reinterpret_cast<const unsigned short*>(Lm + pl.lPT);
+            const int npairs = (N * (N - 1)) / 2;
+            // four pairs per trip: the distance tests are independent, only rare close pairs reach the exp
+            for (int q0 = j0; q0 < npairs; q0 += 4 * Gsz) {
+                float s2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u * Gsz;
+                    const unsigned ij = PT[q < npairs ? q : 0];
+                    const float* xi = x + ad * (ij >> 8);
+                    const float* xj = x + ad * (ij & 255u);
+                    float acc2 = 0.f;
+                    for (int k = 0; k < pd; ++k) { const float e = xi[k] - xj[k]; acc2 += e * e; }
+                    s2[u] = (q < npairs) ? acc2 : 3.0e38f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (s2[u] < thr2) {
+                        const float dist = sqrtf(s2[u]);
+                        if (dist < thr) {
+                            const float e = expf(-(dist * dist) / den);
+                            if (e != 1.f) v[2] += e;             // the reference drops entries equal to 1.
+                        }
                     }
                 }
             }
@@ -450,74 +605,71 @@ __device__ void physics_eval(const Ctx& c, const DevPlan& pl, const DevProb& pb,
         TRIG[(t * N + a) * 6 + q] = sn;
         TRIG[(t * N + a) * 6 + 3 + q] = cs;
     }
-    group_reduce<3>(c, pl, v, SC);                              // SC[t*3 + {0,1,2}]
+    group_reduce<3>(c, pl, v);
+}
 
+struct Costs { float L, H, Q, W; };
+
+// Phase 2 (one thread per sample, after physics_sums): the scalars of calcLHQW.  For the quadcopter it
+// also writes -grad_p H of its sample to DZ[s][0..d) and the thrusts to SC (for calcCtrls).
+__device__ Costs physics_finish(const Ctx& c, const DevPlan& pl, const DevProb& pb, int s) {
+    float* Lm = lds;
+    const float* X = Lm + pl.lSB;
+    const float* P = Lm + pl.lG;
+    const int N = pb.nAgents;
+    const bool wantW = want_W(pb);
+    const float sp2 = group_total<3>(c, pl, s, 0), Qraw = group_total<3>(c, pl, s, 1);
+    const float Wv = wantW ? group_total<3>(c, pl, s, 2) : 0.f;
+    Costs o;
     if (pb.kind != NOCF_PROB_QUADCOPTER) {
-        for (int tt = 0; tt < T; ++tt)
-            for (int i = c.tid; i < d; i += c.nthreads) DZ[tt * pl.ZLD + i] = -P[tt * pl.GLD + i];
-        if (c.tid < T) {
-            const int s = c.tid;
-            const float sp2 = SC[s * 3 + 0], Qraw = SC[s * 3 + 1], Wv = wantW ? SC[s * 3 + 2] : 0.f;
-            float Lg, Qret;
-            if (pb.kind == NOCF_PROB_CROSS2D) { Qret = (float)pb.alphQ * Qraw; Lg = 0.5f * sp2 + Qret; }
-            else { Qret = Qraw; Lg = 0.5f * sp2 + (float)pb.alphQ * Qraw; }
-            if (wantW) Lg = Lg + (float)pb.alphW * Wv;
-            const float H = -Lg + sp2;
-            float* dz = DZ + s * pl.ZLD;
-            dz[d] = Lg;
-            dz[d + 1] = fabsf(P[s * pl.GLD + d] - H);
-            dz[d + 2] = Qret;
-            dz[d + 3] = Wv;
-            if (LHQW) { LHQW[s * 4 + 0] = Lg; LHQW[s * 4 + 1] = H; LHQW[s * 4 + 2] = Qret; LHQW[s * 4 + 3] = Wv; }
-        }
-    } else if (c.tid < T) {
-        const int s = c.tid;
-        const float* xs = X + s * pl.LDs;
-        const float* ps = P + s * pl.GLD;
-        float* dz = DZ + s * pl.ZLD;
-        const float mass = (float)pb.mass, grav = (float)pb.grav;
-        const float Qret = 0.f;                                  // Quadcopter.py:116-122: no obstacle implemented
-        float Lg = (float)pb.alphQ * Qret;
-        float Wv = 0.f;
-        if (wantW) { Wv = SC[s * 3 + 2]; Lg = Lg + (float)pb.alphW * Wv; }
-        float H = 0.f;
-        for (int a = 0; a < N; ++a) {
-            const float* xa = xs + 12 * a;
-            const float* pa = ps + 12 * a;
-            const float* tr = TRIG + (s * N + a) * 6;
-            const float sps = tr[0], sth = tr[1], sph = tr[2], cps = tr[3], cth = tr[4], cph = tr[5];
-            const float f7 = sps * sph + cps * sth * cph;
-            const float f8 = -cps * sph + sps * sth * cph;
-            const float f9 = cth * cph;
-            const float fsum = f7 * pa[6] + f8 * pa[7] + f9 * pa[8];
-            const float u = (float)(-1.0 / (2.0 * pb.mass)) * fsum;
-            const float sq = pa[9] * pa[9] + pa[10] * pa[10] + pa[11] * pa[11];
-            Lg = Lg + 2.f + u * u + 0.25f * sq;
-            const float s1 = xa[6] * pa[0] + xa[7] * pa[1] + xa[8] * pa[2];
-            const float s2 = xa[9] * pa[3] + xa[10] * pa[4] + xa[11] * pa[5];
-            const float um = u / mass;
-            H = H - Lg - s1 - s2 - um * fsum + grav * pa[8] + 0.5f * sq;
-            float* da = dz + 12 * a;
-            for (int k = 0; k < 6; ++k) da[k] = xa[6 + k];
-            da[6] = um * f7; da[7] = um * f8; da[8] = um * f9 - grav;
-            da[9] = -0.5f * pa[9]; da[10] = -0.5f * pa[10]; da[11] = -0.5f * pa[11];
-            SC[T * 3 + s * N + a] = u;                           // thrust, for calcCtrls
-        }
-        dz[d] = Lg;
-        dz[d + 1] = fabsf(ps[d] - H);
-        dz[d + 2] = Qret;
-        dz[d + 3] = Wv;
-        if (LHQW) { LHQW[s * 4 + 0] = Lg; LHQW[s * 4 + 1] = H; LHQW[s * 4 + 2] = Qret; LHQW[s * 4 + 3] = Wv; }
+        float Lg;
+        if (pb.kind == NOCF_PROB_CROSS2D) { o.Q = (float)pb.alphQ * Qraw; Lg = 0.5f * sp2 + o.Q; }
+        else { o.Q = Qraw; Lg = 0.5f * sp2 + (float)pb.alphQ * Qraw; }
+        if (wantW) Lg = Lg + (float)pb.alphW * Wv;
+        o.L = Lg; o.H = -Lg + sp2; o.W = Wv;
+        return o;
     }
-    __syncthreads();
+    const float* xs = X + s * pl.LDs;
+    const float* ps = P + s * pl.GLD;
+    float* dz = Lm + pl.lDZ + s * pl.ZLD;
+    float* SC = Lm + pl.lSC;
+    const float* TRIG = Lm + pl.lTRIG;
+    const float mass = (float)pb.mass, grav = (float)pb.grav;
+    o.Q = 0.f;                                                   // Quadcopter.py:116-122: no obstacle implemented
+    float Lg = (float)pb.alphQ * o.Q;
+    if (wantW) Lg = Lg + (float)pb.alphW * Wv;
+    float H = 0.f;
+    for (int a = 0; a < N; ++a) {
+        const float* xa = xs + 12 * a;
+        const float* pa = ps + 12 * a;
+        const float* tr = TRIG + (s * N + a) * 6;
+        const float sps = tr[0], sth = tr[1], sph = tr[2], cps = tr[3], cth = tr[4], cph = tr[5];
+        const float f7 = sps * sph + cps * sth * cph;
+        const float f8 = -cps * sph + sps * sth * cph;
+        const float f9 = cth * cph;
+        const float fsum = f7 * pa[6] + f8 * pa[7] + f9 * pa[8];
+        const float u = (float)(-1.0 / (2.0 * pb.mass)) * fsum;
+        const float sq = pa[9] * pa[9] + pa[10] * pa[10] + pa[11] * pa[11];
+        Lg = Lg + 2.f + u * u + 0.25f * sq;
+        const float s1 = xa[6] * pa[0] + xa[7] * pa[1] + xa[8] * pa[2];
+        const float s2 = xa[9] * pa[3] + xa[10] * pa[4] + xa[11] * pa[5];
+        const float um = u / mass;
+        H = H - Lg - s1 - s2 - um * fsum + grav * pa[8] + 0.5f * sq;     // running L, like the reference loop
+        float* da = dz + 12 * a;
+        for (int k = 0; k < 6; ++k) da[k] = xa[6 + k];
+        da[6] = um * f7; da[7] = um * f8; da[8] = um * f9 - grav;
+        da[9] = -0.5f * pa[9]; da[10] = -0.5f * pa[10]; da[11] = -0.5f * pa[11];
+        SC[s * N + a] = u;
+    }
+    o.L = Lg; o.H = H; o.W = Wv;
+    return o;
 }
 
 // controls for the T samples from (x = SB, p = G) -> global rows; Cross2D.py:164-165,
-// SwarmTraj.py:166-167, Quadcopter.py:165-174.  Needs physics_eval to have run on the same (x,p)
-// for the quadcopter (thrust in SC).
+// SwarmTraj.py:166-167, Quadcopter.py:165-174 (thrusts were left in SC by physics_finish).
 __device__ void ctrl_write(const Ctx& c, const DevPlan& pl, const DevProb& pb, float* out, long row0, long n, int cdim) {
-    const float* P = c.lds + pl.lG;
-    const float* SC = c.lds + pl.lSC;
+    const float* P = lds + pl.lG;
+    const float* SC = lds + pl.lSC;
     for (int t = 0; t < pl.T; ++t) {
         if (row0 + t >= n) break;
         float* o = out + (row0 + t) * cdim;
@@ -526,7 +678,7 @@ __device__ void ctrl_write(const Ctx& c, const DevPlan& pl, const DevProb& pb, f
         } else {
             for (int i = c.tid; i < cdim; i += c.nthreads) {
                 const int a = i >> 2, q = i & 3;
-                o[i] = (q == 0) ? SC[pl.T * 3 + t * pb.nAgents + a] : -0.5f * P[t * pl.GLD + 12 * a + 8 + q];
+                o[i] = (q == 0) ? SC[t * pb.nAgents + a] : -0.5f * P[t * pl.GLD + 12 * a + 8 + q];
             }
         }
     }
@@ -540,23 +692,25 @@ struct RollArgs {
     double t0, t1, h; int nt, stepper;
     float a0;
     float* z_out; float* persample; float* zFull; float* ctrlFull; int cdim;
+    unsigned long long* stamps;
 };
 
 template <int S>
-__global__ void __launch_bounds__(512) rollout_kernel(DevPlan pl, DevProb pb, const float* __restrict__ ws, RollArgs ra) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan* __restrict__ plp, DevProb pb, const float* __restrict__ ws, RollArgs ra) {
+    const DevPlan& pl = *plp;                       // lives in the workspace: fields are scalar loads, not 60 pinned SGPRs
     Ctx c;
-    c.lds = lds; c.ws = ws;
-    c.tid = threadIdx.x; c.nthreads = blockDim.x; c.wave = threadIdx.x >> 6; c.lane = threadIdx.x & 63;
+    ctx_init(c, ws, (unsigned)(pl.oPlan * 4));
     const int T = pl.T, d = pl.d, ZLD = pl.ZLD;
     const long row0 = (long)blockIdx.x * T;
     float* SB = lds + pl.lSB;
     float* Z0 = lds + pl.lZ0;
     float* ZA = lds + pl.lZA;
     float* DZ = lds + pl.lDZ;
+    const float* G = lds + pl.lG;
 
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
     __syncthreads();
+    build_pair_table(c, pl, pb);
     for (int t = 0; t < T; ++t) {
         long row = row0 + t; if (row >= ra.n) row = ra.n - 1;          // tail rows replicate a valid sample
         for (int i = c.tid; i < d; i += c.nthreads) {
@@ -582,8 +736,9 @@ __global__ void __launch_bounds__(512) rollout_kernel(DevPlan pl, DevProb pb, co
     double tk = ra.t0;
     const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
     const int nsub = nstage + (ra.zFull ? 1 : 0);
-    // One call site for phi_eval/physics_eval: steps k < nt run the RK stages (plus, with
-    // intermediates, the control evaluation); the extra pass k == nt is the terminal evaluation.
+    const bool quad = (pb.kind == NOCF_PROB_QUADCOPTER);
+    // One call site for phi_eval: steps k < nt run the RK stages (plus, with intermediates, the
+    // control evaluation); the extra pass k == nt is the terminal evaluation.
     for (int k = 0; k <= ra.nt; ++k) {
         const bool fin = (k == ra.nt);
         const double t1k = tk + ra.h;
@@ -595,62 +750,81 @@ __global__ void __launch_bounds__(512) rollout_kernel(DevPlan pl, DevProb pb, co
         for (int st = 0; st < (fin ? 1 : nsub); ++st) {
             phi_eval<S>(c, pl, fin);
             if (fin) break;
-            physics_eval(c, pl, pb, nullptr);
+            physics_sums(c, pl, pb);
+            STAMP(c, 8);
             if (st < nstage) {
-                // ---- RK update (src/OCflow.py:143-184), elementwise over the d+4 components
+                // ---- RK update (src/OCflow.py:143-184): z_next accumulates, SB receives the next stage state
                 double tnext;
                 if (nstage == 1) tnext = t1k;
                 else tnext = (st < 2) ? (tk + hsd / 2) : (st == 2 ? (tk + hsd) : t1k);
                 const bool last = (st == nstage - 1);
                 // with intermediates the next evaluation is the control at (z_{k+1}, (tk+h)-h), src/OCflow.py:53
                 if (last && ra.zFull) tnext = t1k - ra.h;
-                for (int t = 0; t < T; ++t)
-                    for (int i = c.tid; i < d + 4; i += c.nthreads) {
-                        const float K = hs * DZ[t * ZLD + i];
-                        const float z0 = Z0[t * ZLD + i];
-                        float xs;
-                        if (nstage == 1) { xs = z0 + K; Z0[t * ZLD + i] = xs; }
-                        else if (st == 0) { ZA[t * ZLD + i] = z0 + c16 * K; xs = z0 + 0.5f * K; }
-                        else if (st == 1) { ZA[t * ZLD + i] += c26 * K; xs = z0 + 0.5f * K; }
-                        else if (st == 2) { ZA[t * ZLD + i] += c26 * K; xs = z0 + K; }
-                        else { xs = ZA[t * ZLD + i] + c16 * K; Z0[t * ZLD + i] = xs; }
-                        if (i < d) SB[t * pl.LDs + i] = xs;
-                        else if (i == d) SB[t * pl.LDs + d] = (float)tnext;
-                        if (last && ra.zFull && row0 + t < ra.n)
-                            ra.zFull[((long)(k + 1) * ra.n + row0 + t) * (d + 4) + i] = xs;
-                    }
+                auto rk = [&](int t, int i, float dzi) {
+                    const float K = hs * dzi;
+                    const float z0 = Z0[t * ZLD + i];
+                    float xs;
+                    if (nstage == 1) { xs = z0 + K; Z0[t * ZLD + i] = xs; }
+                    else if (st == 0) { ZA[t * ZLD + i] = z0 + c16 * K; xs = z0 + 0.5f * K; }
+                    else if (st == 1) { ZA[t * ZLD + i] += c26 * K; xs = z0 + 0.5f * K; }
+                    else if (st == 2) { ZA[t * ZLD + i] += c26 * K; xs = z0 + K; }
+                    else { xs = ZA[t * ZLD + i] + c16 * K; Z0[t * ZLD + i] = xs; }
+                    if (i < d) SB[t * pl.LDs + i] = xs;
+                    if (last && ra.zFull && row0 + t < ra.n)
+                        ra.zFull[((long)(k + 1) * ra.n + row0 + t) * (d + 4) + i] = xs;
+                };
+                if (!quad) {
+                    for (int t = 0; t < T; ++t)
+                        for (int i = c.tid; i < d; i += c.nthreads) rk(t, i, -G[t * pl.GLD + i]);   // dx = -grad_p H = -p
+                }
+                if (c.tid < T) {
+                    const int s = c.tid;
+                    const Costs cs = physics_finish(c, pl, pb, s);
+                    if (quad) for (int i = 0; i < d; ++i) rk(s, i, DZ[s * ZLD + i]);
+                    rk(s, d, cs.L);
+                    rk(s, d + 1, fabsf(G[s * pl.GLD + d] - cs.H));
+                    rk(s, d + 2, cs.Q);
+                    rk(s, d + 3, cs.W);
+                    SB[s * pl.LDs + d] = (float)tnext;
+                }
             } else {
+                if (quad && c.tid < T) (void)physics_finish(c, pl, pb, c.tid);     // thrusts for calcCtrls
+                if (quad) __syncthreads();
                 ctrl_write(c, pl, pb, ra.ctrlFull + (long)(k + 1) * ra.n * ra.cdim, row0, ra.n, ra.cdim);
                 if (c.tid < T) SB[c.tid * pl.LDs + d] = (float)t1k;
             }
             __syncthreads();
+            STAMP(c, 9);
         }
         tk += ra.h;
     }
+#ifdef NOCF_STAMPS
+    if (ra.stamps && c.tid == 0)
+        for (int i = 0; i < 12; ++i) ra.stamps[(long)blockIdx.x * 12 + i] = c.acc[i];
+#endif
 
     // ---- terminal costs (src/OCflow.py:58-76)
     {
         const int Gsz = c.nthreads / T;
         const int t = c.tid / Gsz, j0 = c.tid - t * Gsz;
-        const float* g = lds + pl.lG + t * pl.GLD;
+        const float* g = G + t * pl.GLD;
         float v[2] = {0.f, 0.f};
         for (int i = j0; i < d; i += Gsz) {
             const float res = Z0[t * ZLD + i] - pb.xtarget[i];
             v[0] += res * res;
             v[1] += fabsf(g[i] - ra.a0 * res);
         }
-        float* SC = lds + pl.lSC;
-        group_reduce<2>(c, pl, v, SC);
+        group_reduce<2>(c, pl, v);
         if (c.tid < T && row0 + c.tid < ra.n) {
             const int s = c.tid;
             const long row = row0 + s;
-            const float cG = 0.5f * SC[s * 2 + 0];
+            const float cG = 0.5f * group_total<2>(c, pl, s, 0);
             const float* z = Z0 + s * ZLD;
             if (ra.persample) {
                 float* o = ra.persample + row * 7;
                 o[0] = z[d]; o[1] = cG; o[2] = z[d + 1];
                 o[3] = fabsf(lds[pl.lPHI + s] - ra.a0 * cG);
-                o[4] = SC[s * 2 + 1];
+                o[4] = group_total<2>(c, pl, s, 1);
                 o[5] = z[d + 2]; o[6] = z[d + 3];
             }
         }
@@ -665,12 +839,11 @@ __global__ void __launch_bounds__(512) rollout_kernel(DevPlan pl, DevProb pb, co
 // stand-alone Phi.getGrad / Phi.forward and problem physics (same device code as the rollout)
 // ------------------------------------------------------------------------------------------
 template <int S>
-__global__ void __launch_bounds__(512) phi_kernel(DevPlan pl, const float* __restrict__ ws, const float* __restrict__ s,
+__global__ void __launch_bounds__(NOCF_MAXTHREADS) phi_kernel(const DevPlan* __restrict__ plp, const float* __restrict__ ws, const float* __restrict__ s,
                                                   long n, float* grad, float* value) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DevPlan& pl = *plp;
     Ctx c;
-    c.lds = lds; c.ws = ws;
-    c.tid = threadIdx.x; c.nthreads = blockDim.x; c.wave = threadIdx.x >> 6; c.lane = threadIdx.x & 63;
+    ctx_init(c, ws, (unsigned)(pl.oPlan * 4));
     const int T = pl.T, D1 = pl.D1;
     const long row0 = (long)blockIdx.x * T;
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
@@ -690,14 +863,13 @@ __global__ void __launch_bounds__(512) phi_kernel(DevPlan pl, const float* __res
 __global__ void __launch_bounds__(512) prob_kernel(DevPlan pl, DevProb pb, const float* __restrict__ x,
                                                    const float* __restrict__ p, long n,
                                                    float* lhqw, float* gradpH, float* ctrls, int cdim) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     Ctx c;
-    c.lds = lds; c.ws = nullptr;
-    c.tid = threadIdx.x; c.nthreads = blockDim.x; c.wave = threadIdx.x >> 6; c.lane = threadIdx.x & 63;
+    ctx_init(c, x, 0);                              // no packed weights here; the descriptor is unused
     const int T = pl.T, d = pl.d;
     const long row0 = (long)blockIdx.x * T;
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
     __syncthreads();
+    build_pair_table(c, pl, pb);
     for (int t = 0; t < T; ++t) {
         long row = row0 + t; if (row >= n) row = n - 1;
         for (int i = c.tid; i < d; i += c.nthreads) {
@@ -706,13 +878,22 @@ __global__ void __launch_bounds__(512) prob_kernel(DevPlan pl, DevProb pb, const
         }
     }
     __syncthreads();
-    float* LH = lds + pl.lPART;                  // scratch for (L,H,Q,W)
-    physics_eval(c, pl, pb, LH);
-    for (int t = 0; t < T; ++t) {
-        if (row0 + t >= n) break;
-        if (lhqw && c.tid < 4) lhqw[(row0 + t) * 4 + c.tid] = LH[t * 4 + c.tid];
-        if (gradpH) for (int i = c.tid; i < d; i += c.nthreads) gradpH[(row0 + t) * d + i] = -lds[pl.lDZ + t * pl.ZLD + i];
+    physics_sums(c, pl, pb);
+    if (c.tid < T) {
+        const Costs cs = physics_finish(c, pl, pb, c.tid);
+        if (lhqw && row0 + c.tid < n) {
+            float* o = lhqw + (row0 + c.tid) * 4;
+            o[0] = cs.L; o[1] = cs.H; o[2] = cs.Q; o[3] = cs.W;
+        }
     }
+    __syncthreads();
+    const bool quad = (pb.kind == NOCF_PROB_QUADCOPTER);
+    if (gradpH)
+        for (int t = 0; t < T; ++t) {
+            if (row0 + t >= n) break;
+            for (int i = c.tid; i < d; i += c.nthreads)     // grad_p H = p, or minus the quadcopter's state velocity
+                gradpH[(row0 + t) * d + i] = quad ? -lds[pl.lDZ + t * pl.ZLD + i] : lds[pl.lG + t * pl.GLD + i];
+        }
     if (ctrls) ctrl_write(c, pl, pb, ctrls, row0, n, cdim);
 }
 
@@ -746,11 +927,14 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
-static int choose_sk(int nblk, int chunks, int nwaves) {
+// split-K factor minimising the makespan (in ring turns of 16 k-quads) of nblk column blocks over nwaves waves
+static int choose_sk(int nblk, int pairs, int nwaves, int cap) {
+    // makespan in ring turns; every unit pays ~2 turns of pipeline fill (its first loads are not overlapped),
+    // a split costs one more barrier + an LDS pass
     int best = 1; long bestCost = -1;
-    for (int sk = 1; sk <= MAX_SK && sk <= chunks; ++sk) {
+    for (int sk = 1; sk <= cap && sk <= pairs; ++sk) {
         const long rounds = cdiv(nblk * sk, nwaves);
-        const long cost = rounds * cdiv(chunks, sk) * 8 + sk;       // makespan in chunks, mild penalty per split
+        const long cost = rounds * (cdiv(pairs, sk) + 2) * 32 + (sk > 1 ? 24 + 2 * sk : 0);
         if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = sk; }
     }
     return best;
@@ -763,58 +947,70 @@ static int env_int(const char* name, int dflt) {
 
 // fills the shape / image part of the plan; returns 0 or an NOCF_E_* code
 static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
-    if (d < 1 || m < 1 || nTh < 2 || nTh > MAX_NTH || r < 1 || r > d + 1) return NOCF_E_SHAPE;
+    if (d < 1 || m < 1 || nTh < 2 || nTh > MAX_NTH || r < 1 || r > d + 1 || r > ZQLD) return NOCF_E_SHAPE;
+    if (n_agents > 255) return NOCF_E_SHAPE;
     DevPlan pl;
     memset(&pl, 0, sizeof(pl));
-    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.ME = m + r; pl.nTh = nTh;
-    pl.MB = cdiv(m, 64); pl.MBE = cdiv(pl.ME, 64); pl.DB = cdiv(pl.D1, 64);
-    pl.KQ1 = rup(cdiv(pl.D1, 4), UN); pl.KQ6 = rup(cdiv(pl.ME, 4), UN); pl.KQm = rup(cdiv(m, 4), UN);
+    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh;
+    pl.MB = cdiv(m, 64); pl.DB = cdiv(pl.D1, 64);
+    pl.KQ1 = rup(cdiv(pl.D1, 4), 2 * HALF); pl.KQm = rup(cdiv(m, 4), 2 * HALF);
     // geometry: waves per workgroup and sample sub-tiles
     int nw = 1;
-    while (nw < 8 && nw < pl.MBE) nw *= 2;
+    while (nw < NOCF_MAXTHREADS / 64 && nw < pl.MB) nw *= 2;
     int S = 1;
     nw = env_int("NOCF_NWAVES", nw);
     S = env_int("NOCF_SUBTILES", S);
-    if (!(nw == 1 || nw == 2 || nw == 4 || nw == 8) || !(S == 1 || S == 2 || S == 4)) return NOCF_E_SHAPE;
+    if (!(nw == 1 || nw == 2 || nw == 4 || nw == 8) || nw * 64 > NOCF_MAXTHREADS || !(S == 1 || S == 2 || S == 4)) return NOCF_E_SHAPE;
     pl.nwaves = nw; pl.T = 4 * S;
-    pl.SK1 = choose_sk(pl.MBE, pl.KQ1 / UN, nw);
-    pl.SK6 = choose_sk(pl.DB, pl.KQ6 / UN, nw);
-    pl.SKm = choose_sk(pl.MB, pl.KQm / UN, nw);
-    const int skmax = std::max(pl.SK1, std::max(pl.SK6, pl.SKm));
     // LDS row strides: 64j+4 floats keeps the four sample rows of an A-operand read on distinct 16-B slots
-    const int kmaxH = std::max(pl.KQ6, pl.KQm) * 4;
-    pl.LD = rup(std::max(kmaxH, pl.MBE * 64), 64) + 4;
+    pl.LD = rup(std::max(pl.KQm * 4, pl.MB * 64), 64) + 4;
     pl.LDs = rup(pl.KQ1 * 4, 64) + 4;
-    pl.PLD = std::max(pl.MBE, pl.DB) * 64;
     pl.GLD = pl.DB * 64;
     pl.ZLD = rup(d + 4, 4);
     // packed images
     long o4 = 0;
-    pl.oW0f = o4; o4 += (long)pl.MBE * pl.KQ1 * 64;
-    pl.oW0b = o4; o4 += (long)pl.DB * pl.KQ6 * 64;
+    pl.oW0f = o4; o4 += (long)pl.MB * pl.KQ1 * 64;
+    pl.oW0b = o4; o4 += (long)pl.DB * pl.KQm * 64;
     pl.strideW = (long)pl.MB * pl.KQm * 64;
     pl.oWf = o4; o4 += (long)(nTh - 1) * pl.strideW;
     pl.oWb = o4; o4 += (long)(nTh - 1) * pl.strideW;
     long of = o4 * 4;
-    pl.ob0 = of; of += (long)pl.MBE * 64;
+    pl.ob0 = of; of += (long)pl.MB * 64;
     pl.ob = of; of += (long)(nTh - 1) * pl.MB * 64;
     pl.ow = of; of += (long)pl.MB * 64;
     pl.ocw = of; of += (long)pl.DB * 64;
-    // LDS carve
+    pl.oA = of; of += rup(r * (d + 1), 4);
+    pl.oPlan = of;
+    // LDS carve; the split-K cap shrinks until the partial-sum slots fit next to the activations
     const int T = pl.T;
+    const int npairs = (n_agents * (n_agents - 1)) / 2;
     int l = 0;
-    auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
-    pl.lSB = take(T * pl.LDs);
-    pl.lU0 = take(T * pl.LD); pl.lU1 = take(T * pl.LD);
-    pl.lTH = take((nTh - 1) * T * pl.LD);
-    pl.lAV = take(T * pl.LD); pl.lV = take(T * pl.LD);
-    pl.lPART = take(std::max(skmax * T * pl.PLD, T * 4));
-    pl.lG = take(T * pl.GLD);
-    pl.lZ0 = take(T * pl.ZLD); pl.lZA = take(T * pl.ZLD); pl.lDZ = take(T * pl.ZLD);
-    pl.lRED = take(std::max(T, nw) * 4);
-    pl.lSC = take(T * 3 + T * std::max(1, n_agents) + 8);
-    pl.lPHI = take(T);
-    pl.lTRIG = take(T * std::max(1, n_agents) * 6);
+    for (int cap = MAX_SK; cap >= 1; cap >>= 1) {
+        pl.SK1 = choose_sk(pl.MB, pl.KQ1 / (2 * HALF), nw, cap);
+        pl.SK6 = choose_sk(pl.DB, pl.KQm / (2 * HALF), nw, cap);
+        pl.SKm = choose_sk(pl.MB, pl.KQm / (2 * HALF), nw, cap);
+        int partFloats = 4;
+        if (pl.SK1 > 1) partFloats = std::max(partFloats, pl.SK1 * T * pl.MB * 64);
+        if (pl.SKm > 1) partFloats = std::max(partFloats, pl.SKm * T * pl.MB * 64);
+        if (pl.SK6 > 1) partFloats = std::max(partFloats, pl.SK6 * T * pl.DB * 64);
+        l = 0;
+        auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
+        pl.lSB = take(T * pl.LDs);
+        pl.lU0 = take(T * pl.LD); pl.lU1 = take(T * pl.LD);
+        pl.lTH = take((nTh - 1) * T * pl.LD);
+        pl.lAV = take(T * pl.LD); pl.lV0 = take(T * pl.LD); pl.lV1 = take(T * pl.LD);
+        pl.lPART = take(partFloats);
+        pl.lG = take(T * pl.GLD);
+        pl.lZQ = take(T * ZQLD);
+        pl.lZ0 = take(T * pl.ZLD); pl.lZA = take(T * pl.ZLD); pl.lDZ = take(T * pl.ZLD);
+        pl.lRED = take(std::max(T, nw) * 4);
+        pl.lSC = take(T * std::max(1, n_agents) + 8);
+        pl.lPHI = take(T);
+        pl.lTRIG = take(T * std::max(1, n_agents) * 6);
+        pl.lPT = take((npairs + 1) / 2 + 1);
+        take(64);                                   // slack: the activation ring's last prefetch reads 32 floats past a row
+        if ((size_t)l * 4 <= 160 * 1024) break;
+    }
     pl.ldsFloats = l;
     if ((size_t)l * 4 > 160 * 1024) return NOCF_E_LDS;
     pl.hN = (float)(1.0 / (nTh - 1));
@@ -823,7 +1019,7 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
 }
 
 static size_t plan_ws_bytes(const DevPlan& pl) {
-    return (size_t)(pl.ocw + (long)pl.DB * 64) * sizeof(float);
+    return (size_t)pl.oPlan * sizeof(float) + ((sizeof(DevPlan) + 15) / 16) * 16;
 }
 
 static int fill_prob(const NocfProb* prob, int d, DevProb* pb) {
@@ -873,13 +1069,24 @@ static int check_phi(const NocfPhi* phi) {
 // launch stream immediately around the kernel, so the figure is the kernel's own duration.
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static bool g_prof_on = false;
+static unsigned long long* g_stamp_buf = nullptr;     // diagnostic builds only (nocf_debug_set_stamp_buffer)
 
 extern "C" {
 
 int nocf_version(void) { return NOCF_VERSION; }
 
+int nocf_debug_set_stamp_buffer(void* device_buf) {
+#ifdef NOCF_STAMPS
+    g_stamp_buf = (unsigned long long*)device_buf;
+    return 0;
+#else
+    (void)device_buf;
+    return NOCF_E_SHAPE;                                 // production build carries no stamps
+#endif
+}
+
 int nocf_profile_begin(void) {
-    for (auto& pr : g_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : g_prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     g_prof_events.clear();
     g_prof_on = true;
     return 0;
@@ -898,7 +1105,7 @@ int nocf_profile_end(double* total_ms, int32_t* launches) {
     }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = (int32_t)g_prof_events.size();
-    for (auto& pr : g_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : g_prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     g_prof_events.clear();
     return 0;
 }
@@ -938,11 +1145,13 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     float* ws = (float*)workspace;
     rc = pack_weights(pl, phi, ws, st);
     if (rc) return rc;
+    const DevPlan* plp = reinterpret_cast<const DevPlan*>(ws + pl.oPlan);
     RollArgs ra;
     ra.x = x; ra.n = n; ra.t0 = t0; ra.t1 = t1; ra.h = (t1 - t0) / nt; ra.nt = nt; ra.stepper = stepper;
     ra.a0 = alph[0];
     ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull;
     ra.cdim = nocf_ctrl_dim(prob, phi->d);
+    ra.stamps = g_stamp_buf;
     const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
     const int grid = (int)((n + pl.T - 1) / pl.T);
     const int block = pl.nwaves * 64;
@@ -950,19 +1159,19 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_prof_on) {
         if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
-        hipEventRecord(ev0, st);
+        (void)hipEventRecord(ev0, st);
     }
     switch (pl.T / 4) {
         case 1: e = set_lds(rollout_kernel<1>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(rollout_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, pl, pb, ws, ra); break;
+                hipLaunchKernelGGL(rollout_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
         case 2: e = set_lds(rollout_kernel<2>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(rollout_kernel<2>, dim3(grid), dim3(block), ldsBytes, st, pl, pb, ws, ra); break;
+                hipLaunchKernelGGL(rollout_kernel<2>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
         default: e = set_lds(rollout_kernel<4>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(rollout_kernel<4>, dim3(grid), dim3(block), ldsBytes, st, pl, pb, ws, ra); break;
+                hipLaunchKernelGGL(rollout_kernel<4>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
     }
     e = hipGetLastError();
     if (e) return (int)e;
-    if (g_prof_on) { hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
+    if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
     if (cost_sums) {
         hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums);
         e = hipGetLastError();
@@ -986,17 +1195,18 @@ static int phi_common(const NocfPhi* phi, const float* s, int64_t n, float* grad
     float* ws = (float*)workspace;
     rc = pack_weights(pl, phi, ws, st);
     if (rc) return rc;
+    const DevPlan* plp = reinterpret_cast<const DevPlan*>(ws + pl.oPlan);
     const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
     const int grid = (int)((n + pl.T - 1) / pl.T);
     const int block = pl.nwaves * 64;
     hipError_t e;
     switch (pl.T / 4) {
         case 1: e = set_lds(phi_kernel<1>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(phi_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, pl, ws, s, (long)n, grad, value); break;
+                hipLaunchKernelGGL(phi_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, plp, ws, s, (long)n, grad, value); break;
         case 2: e = set_lds(phi_kernel<2>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(phi_kernel<2>, dim3(grid), dim3(block), ldsBytes, st, pl, ws, s, (long)n, grad, value); break;
+                hipLaunchKernelGGL(phi_kernel<2>, dim3(grid), dim3(block), ldsBytes, st, plp, ws, s, (long)n, grad, value); break;
         default: e = set_lds(phi_kernel<4>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(phi_kernel<4>, dim3(grid), dim3(block), ldsBytes, st, pl, ws, s, (long)n, grad, value); break;
+                hipLaunchKernelGGL(phi_kernel<4>, dim3(grid), dim3(block), ldsBytes, st, plp, ws, s, (long)n, grad, value); break;
     }
     return (int)hipGetLastError();
 }

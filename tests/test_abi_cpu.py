@@ -30,10 +30,11 @@ def test_every_declared_symbol_is_exported(L):
 
 
 def test_workspace_sizes(L):
-    # swarm50: 9*40*64 + 3*136*64 + 2*8*128*64 float4 images + padded vectors
-    n4 = 9 * 40 * 64 + 3 * 136 * 64 + 2 * 8 * 128 * 64
-    nv = 9 * 64 + 8 * 64 + 8 * 64 + 3 * 64
-    assert L.nocf_workspace_bytes(150, 512, 2) == (n4 * 4 + nv) * 4
+    # swarm50: opening 8*48*64 + closing 3*128*64 + (forward, backward) 2*8*128*64 float4 images + padded vectors
+    n4 = 8 * 48 * 64 + 3 * 128 * 64 + 2 * 8 * 128 * 64
+    nv = 8 * 64 + 8 * 64 + 8 * 64 + 3 * 64 + 10 * 151 + 2          # ... + the copy of A (padded to 4 floats)
+    got = L.nocf_workspace_bytes(150, 512, 2)
+    assert (n4 * 4 + nv) * 4 < got <= (n4 * 4 + nv) * 4 + 1024          # + the plan record
     assert L.nocf_workspace_bytes(4, 32, 2) > 0
     assert L.nocf_workspace_bytes(4, 32, 1) == 0          # nTh < 2 is rejected (src/Phi.py:25-27)
 

@@ -154,7 +154,10 @@ def test_intermediates_against_reference_golden(golden, tag):
     assert bad == 0, f"{g.name} {tag}: {bad} state entries off (worst {worst:g})"
     bad, worst = count_off(zF[:, d:], zw[:, d:], 1e-3, 1e-3)
     assert bad <= 4, f"{g.name} {tag}: {bad} running-cost entries off (worst {worst:g})"
-    bad, worst = count_off(cF, cw, 1e-4, 1e-3)
+    # controls are -grad Phi (or thrust/torques): sums of m terms far larger than the result, so the
+    # fp32 noise scales with max|ctrl| (the reference's own fp32-vs-fp64 gap reaches 7e-4 at max|ctrl|=65
+    # on swarm50 eval_seg): abs 1e-4*max|ref| + rel 1e-4
+    bad, worst = count_off(cF, cw, 1e-4, 1e-4 * float(cw.abs().max()) + 1e-5)
     assert bad == 0, f"{g.name} {tag}: {bad} control entries off (worst {worst:g})"
     assert float(cF[:, :, 0].abs().max()) == 0.0
 
