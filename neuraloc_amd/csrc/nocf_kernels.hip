@@ -48,7 +48,7 @@ extern __shared__ __attribute__((aligned(16))) float lds[];
 struct DevPlan {
     int d, D1, m, r, nTh;
     int MB, DB;                      // 64-column blocks: hidden width, d+1
-    int KQ1, KQm;                    // k-quads of the two contraction lengths (d+1, m), padded to 2*HALF
+    int KQ1, KQm;                    // k-quads of the two contraction lengths (d+1, m), padded to HALF
     int SK1, SK6, SKm;               // split-K factors of the opening / closing / residual GEMMs
     int LD, LDs, GLD, ZLD;           // LDS row strides (floats)
     int T, nwaves;
@@ -57,6 +57,7 @@ struct DevPlan {
     float hN, cb;
     // LDS carve (float offsets)
     int lSB, lU0, lU1, lTH, lAV, lV0, lV1, lPART, lG, lZQ, lZ0, lZA, lDZ, lRED, lSC, lPHI, lTRIG, lPT;
+    int lVEC, nVEC;                  // biases, w, c.weight and A, copied once per launch (ws floats [ob0, oPlan))
     int ldsFloats;
 };
 
@@ -202,9 +203,11 @@ __device__ __forceinline__ void ctx_init(Ctx& c, const float* ws, unsigned ws_by
 #endif
 }
 
-// one packed k-quad of weights for this lane: 16 B at (uniform byte offset soff) + lane*16
-__device__ __forceinline__ float4 wload(const Ctx& c, int soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.wrs, c.lane * 16, soff, 0);
+// one packed k-quad of weights for this lane: 16 B at (uniform byte offset soff) + voff, voff = lane*16, or
+// WOOB for lanes whose column is padding: the descriptor's range check returns 0 without fetching
+#define WOOB 0x7ffffff0
+__device__ __forceinline__ float4 wload(const Ctx& c, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(c.wrs, voff, soff, 0);
     float4 f;
     f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
     return f;
@@ -218,6 +221,34 @@ __device__ __forceinline__ float4 wload(const Ctx& c, int soff) {
 #define STAMP(c, id) do { } while (0)
 #endif
 
+// The weight ring: two halves of 8 k-quads (8 KiB per wave each).  It lives in the kernel's scope, not
+// in gemm_phase, because the first turn of the NEXT phase is loaded before the current phase's
+// epilogue, barrier and (at the end of an evaluation) the physics: weights do not depend on data.
+struct Ring { float4 A[HALF], B[HALF]; };
+struct PhaseDesc { long img4; int nblk, KQ, SK, ncols; };
+
+__device__ __forceinline__ void unit_range(const PhaseDesc& ph, int u, int& cb, int& ks, int& h0, int& nh) {
+    cb = u / ph.SK; ks = u - cb * ph.SK;
+    const int halves = ph.KQ / HALF;
+    h0 = (halves * ks) / ph.SK;
+    nh = (halves * (ks + 1)) / ph.SK - h0;
+}
+
+__device__ __forceinline__ void ring_preload(const Ctx& c, Ring& rg, const PhaseDesc& ph, int u) {
+    int cb, ks, h0, nh;
+    unit_range(ph, u, cb, ks, h0, nh);
+    const int voff = (cb * 64 + c.lane < ph.ncols) ? c.lane * 16 : WOOB;
+    const int wo = (int)((ph.img4 + ((long)cb * ph.KQ + (long)h0 * HALF) * 64) * 16);
+    if (nh > 0) {
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) rg.A[i] = wload(c, voff, wo + i * 1024);
+    }
+    if (nh > 1) {
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) rg.B[i] = wload(c, voff, wo + (HALF + i) * 1024);
+    }
+}
+
 // One half of the weight ring: 8 k-quads = 32 k-steps = 32*S MFMAs.  Two register rings feed it:
 //   buf[8]  weights of this half; with RW each consumed entry is reloaded with the k-quad 16 further
 //           on (the ring's other half is in flight meanwhile: 8..16 KiB per wave outstanding)
@@ -227,7 +258,7 @@ __device__ __forceinline__ float4 wload(const Ctx& c, int soff) {
 // arithmetic); no branch sits between the loads, so the waits are counted vmcnt/lgkmcnt.
 template <int S, bool RW, bool RA>
 __device__ __forceinline__ void ring_half(const Ctx& c, float4 (&buf)[HALF], float4 (&a)[S][HALF], f32x4 (&acc)[S][4],
-                                          int a_next /*float4 index*/, int ld /*floats*/, int w_next /*bytes*/) {
+                                          int a_next /*float4 index*/, int ld /*floats*/, int voff, int w_next /*bytes*/) {
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
         const float4 w = buf[i];
@@ -240,7 +271,7 @@ __device__ __forceinline__ void ring_half(const Ctx& c, float4 (&buf)[HALF], flo
             acc[s][3] = mfma4(av.w, w.w, acc[s][3]);
             if (RA) a[s][i] = reinterpret_cast<const float4*>(lds)[a_next + s * ld + i];      // float4 index: ds_read_b128
         }
-        if (RW) buf[i] = wload(c, w_next + i * 1024);
+        if (RW) buf[i] = wload(c, voff, w_next + i * 1024);
     }
 }
 
@@ -250,56 +281,68 @@ __device__ __forceinline__ float part_sum(const float* part, int pstride, int SK
     return v;
 }
 
-// out[t][col] = epi(t, col, sum_k act[t][k] * B[k][col]) for nblk 64-column blocks.
-//   img4     float4 offset of the packed image [nblk][KQ][64] in the workspace
+// out[t][col] = epi(t, col, sum_k act[t][k] * B[k][col]) for ph.nblk 64-column blocks.
+//   ph.img4  float4 offset of the packed image [nblk][KQ][64] in the workspace
 //   act_off  float offset in LDS of the activation rows [T][ld]
+//   pre      the ring already holds the first turn of this wave's first unit (loaded by the previous phase)
+//   nxt      the phase that follows (nxt.SK == 0: none); its first turn is loaded as soon as this wave has
+//            consumed its last weights, i.e. before the epilogue and the barrier
 // SK == 1: the wave that owns a column block applies epi straight from its accumulators.
 // SK  > 1: split-K partials go through LDS (fixed-order sum, deterministic); contains one barrier.
 // The caller puts a barrier after the call before anyone reads what epi wrote.
 template <int S, class Epi>
-__device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, long img4,
-                                           int nblk, int KQ, int SK, int act_off, int ld, Epi epi) {
-    const int partLD = nblk * 64;
+__device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring& rg, bool pre, const PhaseDesc& ph,
+                                           const PhaseDesc& nxt, int act_off, int ld, Epi epi, int stamp_id = 11) {
+    const int partLD = ph.nblk * 64;
     const int pstride = pl.T * partLD;
-    const int pairs = KQ / (2 * HALF);             // K is padded to whole ring turns (2 halves)
-    const int units = nblk * SK;
+    const int units = ph.nblk * ph.SK;
     const int arow = c.lane & 3;
+    const bool want_next = nxt.SK > 0 && c.wave < nxt.nblk * nxt.SK;
+    bool next_done = false;
     for (int u = c.wave; u < units; u += pl.nwaves) {
-        const int cb = u / SK, ks = u - cb * SK;
-        const int p0 = (pairs * ks) / SK, p1 = (pairs * (ks + 1)) / SK;
-        const int np = p1 - p0;
+        int cb, ks, h0, nh;
+        unit_range(ph, u, cb, ks, h0, nh);
+        if (!(pre && u == c.wave)) ring_preload(c, rg, ph, u);
         f32x4 acc[S][4];
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[s][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int wo = (int)((img4 + ((long)cb * KQ + (long)p0 * 2 * HALF) * 64) * 16);   // byte offset, wave-uniform
-        int ao = (act_off + arow * ld) / 4 + p0 * 2 * HALF;                         // float4 index, per lane (rows are 16-B aligned)
-        float4 A[HALF], B[HALF], av[S][HALF];
-        if (np > 0) {
+        const int voff = (cb * 64 + c.lane < ph.ncols) ? c.lane * 16 : WOOB;
+        int wo = (int)((ph.img4 + ((long)cb * ph.KQ + (long)h0 * HALF) * 64) * 16);   // byte offset, wave-uniform
+        int ao = (act_off + arow * ld) / 4 + h0 * HALF;                               // float4 index, per lane
+        float4 av[S][HALF];
 #pragma unroll
-            for (int i = 0; i < HALF; ++i) A[i] = wload(c, wo + i * 1024);
+        for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int i = 0; i < HALF; ++i) B[i] = wload(c, wo + (HALF + i) * 1024);
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-                for (int i = 0; i < HALF; ++i) av[s][i] = reinterpret_cast<const float4*>(lds)[ao + s * ld + i];
-        }
-        for (int pr = 0; pr + 1 < np; ++pr) {
-            ring_half<S, true, true>(c, A, av, acc, ao + HALF, ld, wo + 2 * HALF * 1024);
-            ring_half<S, true, true>(c, B, av, acc, ao + 2 * HALF, ld, wo + 3 * HALF * 1024);
+            for (int i = 0; i < HALF; ++i) av[s][i] = reinterpret_cast<const float4*>(lds)[ao + s * ld + i];
+        // halves alternate between rg.A and rg.B; half h is refilled with half h+2 while it is consumed
+        int h = 0;
+        for (; h + 3 < nh; h += 2) {
+            ring_half<S, true, true>(c, rg.A, av, acc, ao + HALF, ld, voff, wo + 2 * HALF * 1024);
+            ring_half<S, true, true>(c, rg.B, av, acc, ao + 2 * HALF, ld, voff, wo + 3 * HALF * 1024);
             wo += 2 * HALF * 1024;
             ao += 2 * HALF;
         }
-        if (np > 0) {
-            ring_half<S, false, true>(c, A, av, acc, ao + HALF, ld, wo);
-            ring_half<S, false, false>(c, B, av, acc, ao, ld, wo);
+        const int rem = nh - h;                         // 1, 2 or 3 halves left
+        if (rem == 3) {
+            ring_half<S, true, true>(c, rg.A, av, acc, ao + HALF, ld, voff, wo + 2 * HALF * 1024);
+            ring_half<S, false, true>(c, rg.B, av, acc, ao + 2 * HALF, ld, voff, wo);
+            ring_half<S, false, false>(c, rg.A, av, acc, ao, ld, voff, wo);
+        } else if (rem == 2) {
+            ring_half<S, false, true>(c, rg.A, av, acc, ao + HALF, ld, voff, wo);
+            ring_half<S, false, false>(c, rg.B, av, acc, ao, ld, voff, wo);
+        } else if (rem == 1) {
+            ring_half<S, false, false>(c, rg.A, av, acc, ao, ld, voff, wo);
+        }
+        if (u + pl.nwaves >= units) {
+            STAMP(c, stamp_id);                          // diagnostic: end of this wave's streaming
+            if (want_next) { ring_preload(c, rg, nxt, c.wave); next_done = true; }
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const f32x4 rsum = (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
-            if (SK == 1) {
+            if (ph.SK == 1) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) epi(4 * s + q, cb * 64 + c.lane, rsum[q]);
             } else {
@@ -309,11 +352,12 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, long
             }
         }
     }
-    if (SK > 1) {
+    if (want_next && !next_done) ring_preload(c, rg, nxt, c.wave);     // waves without a unit in this phase
+    if (ph.SK > 1) {
         __syncthreads();
         for (int t = 0; t < pl.T; ++t)
             for (int col = c.tid; col < partLD; col += c.nthreads)
-                epi(t, col, part_sum(lds + pl.lPART, pstride, SK, t * partLD + col));
+                epi(t, col, part_sum(lds + pl.lPART, pstride, ph.SK, t * partLD + col));
     }
 }
 
@@ -347,24 +391,38 @@ __device__ __forceinline__ float group_total(const Ctx& c, const DevPlan& pl, in
     return s;
 }
 
+// biases, w, c.weight and A: workspace -> LDS, once per launch (before the first barrier of the kernel)
+__device__ __forceinline__ void load_vectors(const Ctx& c, const DevPlan& pl) {
+    for (int i = c.tid; i < pl.nVEC; i += c.nthreads) lds[pl.lVEC + i] = c.ws[pl.ob0 + i];
+}
+
 // ------------------------------------------------------------------------------------------
 // grad Phi (and optionally Phi) for the T samples whose s=[x,t] rows sit in SB.
 // src/Phi.py:99-138 restated per sample row; results: G[t][0..d]; if need_value PHI[t]=Phi(s).
 // Every thread of the workgroup must call it (it contains barriers).
 // ------------------------------------------------------------------------------------------
 template <int S>
-__device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value) {
+__device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring& rg, bool& ring_ready, bool more_evals) {
     const int T = pl.T, LD = pl.LD, m = pl.m, D1 = pl.D1, r = pl.r;
     const int oSB = pl.lSB, oTH = pl.lTH, oAV = pl.lAV, oG = pl.lG, oZQ = pl.lZQ;
     const float hN = pl.hN;
-    const float* b0 = c.ws + pl.ob0;
-    const float* wv = c.ws + pl.ow;
-    const float* cw = c.ws + pl.ocw;
-    const float* Araw = c.ws + pl.oA;
+    // small vectors live in LDS (load_vectors): an epilogue must not issue a global load, it would queue
+    // behind the next phase's weight prefetch (loads return in order)
+    const float* vec = lds + pl.lVEC - pl.ob0;
+    const float* b0 = vec + pl.ob0;
+    const float* wv = vec + pl.ow;
+    const float* cw = vec + pl.ocw;
+    const float* Araw = vec + pl.oA;
     const int lastLayer = pl.nTh - 1;
+    const PhaseDesc phOpen = {pl.oW0f, pl.MB, pl.KQ1, pl.SK1, m};
+    const PhaseDesc phClose = {pl.oW0b, pl.DB, pl.KQm, pl.SK6, D1};
+    const PhaseDesc phNone = {0, 0, 0, 0, 0};
+    auto phFwd = [&](int i) { return PhaseDesc{pl.oWf + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, m}; };
+    auto phBwd = [&](int i) { return PhaseDesc{pl.oWb + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, m}; };
 
-    __syncthreads();
     STAMP(c, 10);
+    // the opening weights do not wait for z: start them first (unless the previous evaluation already did)
+    if (!ring_ready && c.wave < phOpen.nblk * phOpen.SK) ring_preload(c, rg, phOpen, c.wave);
     // ---- z = A s (the low-rank quadratic's inner product; A is at most 10 x (d+1)).  8 lanes share a row.
     {
         const int items = T * r * 8;
@@ -384,7 +442,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value) {
         }
     }
     // ---- opening layer: o = s K0^T + b0 ; u0 = sigma(o) ; gate0 = tanh(o)
-    gemm_phase<S>(c, pl, pl.oW0f, pl.MB, pl.KQ1, pl.SK1, oSB, pl.LDs, [&](int t, int col, float v) {
+    gemm_phase<S>(c, pl, rg, true, phOpen, phFwd(1), oSB, pl.LDs, [&](int t, int col, float v) {
         if (col < m) {
             const float o = v + b0[col];
             float sg, th;
@@ -392,16 +450,16 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value) {
             lds[pl.lU0 + t * LD + col] = sg;
             lds[oTH + t * LD + col] = th;
         }
-    });
+    }, 1);
     __syncthreads();
     STAMP(c, 0);
     int cur = 0;
     // ---- residual layers, forward
     for (int i = 1; i <= lastLayer; ++i) {
-        const float* bi = c.ws + pl.ob + (long)(i - 1) * pl.MB * 64;
+        const float* bi = vec + pl.ob + (long)(i - 1) * pl.MB * 64;
         const int oTHi = oTH + i * T * LD;
         const int oUc = cur ? pl.lU1 : pl.lU0, oUn = cur ? pl.lU0 : pl.lU1;
-        gemm_phase<S>(c, pl, pl.oWf + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, oUc, LD,
+        gemm_phase<S>(c, pl, rg, true, phFwd(i), (i < lastLayer) ? phFwd(i + 1) : phBwd(lastLayer), oUc, LD,
                       [&](int t, int col, float v) {
             if (col < m) {
                 const float q = v + bi[col];
@@ -417,7 +475,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value) {
                     if (need_value) lds[oUn + t * LD + col] = lds[oUc + t * LD + col] + hN * sigma_act(q);
                 }
             }
-        });
+        }, 3);
         __syncthreads();
         cur ^= 1;
     }
@@ -440,26 +498,27 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value) {
     for (int i = lastLayer; i >= 1; --i) {
         const int oTHp = oTH + (i - 1) * T * LD;
         const int oVc = vb ? pl.lV1 : pl.lV0, oVn = vb ? pl.lV0 : pl.lV1;
-        gemm_phase<S>(c, pl, pl.oWb + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, oVc, LD,
+        gemm_phase<S>(c, pl, rg, true, phBwd(i), (i > 1) ? phBwd(i - 1) : phClose, oVc, LD,
                       [&](int t, int col, float v) {
             if (col < m) {
                 const float a = lds[oAV + t * LD + col] + hN * v;
                 lds[oAV + t * LD + col] = a;
                 lds[oVn + t * LD + col] = lds[oTHp + t * LD + col] * a;
             }
-        });
+        }, 5);
         __syncthreads();
         vb ^= 1;
     }
     STAMP(c, 4);
     // ---- closing: g = K0^T (tanh(o) . a) + A^T (A s) + c
-    gemm_phase<S>(c, pl, pl.oW0b, pl.DB, pl.KQm, pl.SK6, vb ? pl.lV1 : pl.lV0, LD, [&](int t, int i, float v) {
+    gemm_phase<S>(c, pl, rg, true, phClose, more_evals ? phOpen : phNone, vb ? pl.lV1 : pl.lV0, LD, [&](int t, int i, float v) {
         if (i < D1) {
             float g = v + cw[i];
             for (int q = 0; q < r; ++q) g += Araw[(long)q * D1 + i] * lds[oZQ + t * ZQLD + q];
             lds[oG + t * pl.GLD + i] = g;
         }
-    });
+    }, 7);
+    ring_ready = more_evals;
     __syncthreads();
     STAMP(c, 6);
 }
@@ -710,6 +769,7 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
 
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
     __syncthreads();
+    load_vectors(c, pl);
     build_pair_table(c, pl, pb);
     for (int t = 0; t < T; ++t) {
         long row = row0 + t; if (row >= ra.n) row = ra.n - 1;          // tail rows replicate a valid sample
@@ -733,6 +793,8 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
     __syncthreads();
 
     const float c16 = (float)(1.0 / 6.0), c26 = (float)(2.0 / 6.0);
+    Ring rg;
+    bool ring_ready = false;
     double tk = ra.t0;
     const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
     const int nsub = nstage + (ra.zFull ? 1 : 0);
@@ -748,7 +810,8 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
             if (c.tid < T) SB[c.tid * pl.LDs + d] = (float)ra.t1;      // src/OCflow.py:62
         }
         for (int st = 0; st < (fin ? 1 : nsub); ++st) {
-            phi_eval<S>(c, pl, fin);
+            // the ring is not carried across evaluations: keeping 64 registers alive through the physics cost spills
+            phi_eval<S>(c, pl, fin, rg, ring_ready, false);
             if (fin) break;
             physics_sums(c, pl, pb);
             STAMP(c, 8);
@@ -848,11 +911,15 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) phi_kernel(const DevPlan* __r
     const long row0 = (long)blockIdx.x * T;
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
     __syncthreads();
+    load_vectors(c, pl);
     for (int t = 0; t < T; ++t) {
         long row = row0 + t; if (row >= n) row = n - 1;
         for (int i = c.tid; i < D1; i += c.nthreads) lds[pl.lSB + t * pl.LDs + i] = s[row * D1 + i];
     }
-    phi_eval<S>(c, pl, value != nullptr);
+    Ring rg;
+    bool ring_ready = false;
+    __syncthreads();
+    phi_eval<S>(c, pl, value != nullptr, rg, ring_ready, false);
     for (int t = 0; t < T; ++t) {
         if (row0 + t >= n) break;
         if (grad) for (int i = c.tid; i < D1; i += c.nthreads) grad[(row0 + t) * D1 + i] = lds[pl.lG + t * pl.GLD + i];
@@ -927,14 +994,14 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
-// split-K factor minimising the makespan (in ring turns of 16 k-quads) of nblk column blocks over nwaves waves
-static int choose_sk(int nblk, int pairs, int nwaves, int cap) {
-    // makespan in ring turns; every unit pays ~2 turns of pipeline fill (its first loads are not overlapped),
-    // a split costs one more barrier + an LDS pass
+// split-K factor minimising the makespan of nblk column blocks over nwaves waves
+static int choose_sk(int nblk, int halves, int nwaves, int cap) {
+    // makespan in ring halves (8 k-quads); a wave's first unit is prefetched by the previous phase, every
+    // further unit pays ~3 halves of pipeline fill; a split costs one more barrier + an LDS pass
     int best = 1; long bestCost = -1;
-    for (int sk = 1; sk <= cap && sk <= pairs; ++sk) {
+    for (int sk = 1; sk <= cap && sk <= halves; ++sk) {
         const long rounds = cdiv(nblk * sk, nwaves);
-        const long cost = rounds * (cdiv(pairs, sk) + 2) * 32 + (sk > 1 ? 24 + 2 * sk : 0);
+        const long cost = (rounds * cdiv(halves, sk) + (rounds - 1) * 3) * 16 + (sk > 1 ? 24 + 2 * sk : 0);
         if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = sk; }
     }
     return best;
@@ -953,7 +1020,7 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
     memset(&pl, 0, sizeof(pl));
     pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh;
     pl.MB = cdiv(m, 64); pl.DB = cdiv(pl.D1, 64);
-    pl.KQ1 = rup(cdiv(pl.D1, 4), 2 * HALF); pl.KQm = rup(cdiv(m, 4), 2 * HALF);
+    pl.KQ1 = rup(cdiv(pl.D1, 4), HALF); pl.KQm = rup(cdiv(m, 4), HALF);
     // geometry: waves per workgroup and sample sub-tiles
     int nw = 1;
     while (nw < NOCF_MAXTHREADS / 64 && nw < pl.MB) nw *= 2;
@@ -986,9 +1053,9 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
     const int npairs = (n_agents * (n_agents - 1)) / 2;
     int l = 0;
     for (int cap = MAX_SK; cap >= 1; cap >>= 1) {
-        pl.SK1 = choose_sk(pl.MB, pl.KQ1 / (2 * HALF), nw, cap);
-        pl.SK6 = choose_sk(pl.DB, pl.KQm / (2 * HALF), nw, cap);
-        pl.SKm = choose_sk(pl.MB, pl.KQm / (2 * HALF), nw, cap);
+        pl.SK1 = choose_sk(pl.MB, pl.KQ1 / HALF, nw, cap);
+        pl.SK6 = choose_sk(pl.DB, pl.KQm / HALF, nw, cap);
+        pl.SKm = choose_sk(pl.MB, pl.KQm / HALF, nw, cap);
         int partFloats = 4;
         if (pl.SK1 > 1) partFloats = std::max(partFloats, pl.SK1 * T * pl.MB * 64);
         if (pl.SKm > 1) partFloats = std::max(partFloats, pl.SKm * T * pl.MB * 64);
@@ -1008,6 +1075,8 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
         pl.lPHI = take(T);
         pl.lTRIG = take(T * std::max(1, n_agents) * 6);
         pl.lPT = take((npairs + 1) / 2 + 1);
+        pl.nVEC = (int)(pl.oPlan - pl.ob0);
+        pl.lVEC = take(pl.nVEC);
         take(64);                                   // slack: the activation ring's last prefetch reads 32 floats past a row
         if ((size_t)l * 4 <= 160 * 1024) break;
     }

@@ -1,0 +1,76 @@
+"""CPU, world_size 2 (gloo): the batch-sharded path -- row split, one SUM all-reduce of the 8-vector
+[7 cost sums, count], means and Jc -- gives the reference's full-batch answer on every rank.
+The per-rank sums come from the checker here (no GPU in this container); on the GPU box the same
+function is fed by the HIP launch (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_golden
+    from util_hip import make_oracle
+    from oracle import ocflow_oracle as orc
+    from neuraloc_amd.distributed import OCflow_sharded, shard_rows
+
+    g = load_golden(name)
+    P, S = make_oracle(g, training=False)
+    m = g.meta
+    x = g.t("x")
+    lo, hi = shard_rows(x.shape[0], rank, world)
+
+    def local_sums(xl):
+        with torch.no_grad():
+            tab = orc.persample_table(xl, P, S, [0.0, 1.0], m["nt"], "rk4", m["alph"])
+        return torch.cat((tab.double().sum(0), torch.tensor([float(xl.shape[0])], dtype=torch.float64))).float()
+
+    Jc, cs = OCflow_sharded(x[lo:hi], None, None, [0.0, 1.0], m["nt"], "rk4", m["alph"], local_rollout=local_sums)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([float(Jc)] + [float(c) for c in cs] + [lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["softcorridor", "swap12"])
+def test_two_rank_sharded_costs_match_the_reference(name, tmp_path):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from conftest import load_golden
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(name)
+    r0 = np.load(tmp_path / "rank0.npy")
+    r1 = np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0[:8], r1[:8]), "ranks disagree after the all-reduce"
+    assert (r0[8], r0[9], r1[8], r1[9]) == (0, 20, 20, 40)
+    want = np.concatenate(([float(g["eval_rk4/Jc"])], g["eval_rk4/cs"].astype(np.float64)))
+    assert np.all(np.abs(r0[:8] - want) <= 1e-5 * np.abs(want) + 1e-7)
+
+
+def test_shard_rows_is_a_partition():
+    from neuraloc_amd.distributed import shard_rows
+    for n in (1, 7, 1024, 1027):
+        for world in (1, 2, 4, 8):
+            edges = [shard_rows(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1

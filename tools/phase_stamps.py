@@ -18,8 +18,9 @@ import bench                                   # noqa: E402
 import neuraloc_amd as na                      # noqa: E402
 from neuraloc_amd import _lib                  # noqa: E402
 
-NAMES = ["z=As + opening GEMM+epi", "-", "forward layers GEMM+epi", "-", "backward GEMM+epi", "-",
-         "closing GEMM+epi", "-", "physics sums", "RK update/finish", "entry barrier", "-"]
+NAMES = ["opening: epilogue+barrier", "opening: z=As + weight stream (wave 0)", "forward: epilogue+barrier", "forward: weight stream",
+         "backward: epilogue+barrier", "backward: weight stream", "closing: split-K sum+epilogue+barrier", "closing: weight stream",
+         "physics sums", "RK update/finish", "entry barrier", "-"]
 
 
 def main():
