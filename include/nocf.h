@@ -87,6 +87,10 @@ int nocf_version(void);
 /* bytes of scratch `workspace` a call with these shapes needs (packed weight images) */
 size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh);
 
+/* bytes a nocf_rollout_f32 call over n samples can use: >= nocf_workspace_bytes; the extra room holds the
+ * activation-exchange buffers of the weight-sliced group kernel (without it the per-tile kernel runs) */
+size_t nocf_rollout_workspace_bytes(int32_t d, int32_t m, int32_t nTh, int64_t n);
+
 /* number of control components per sample: d (Cross2D, SwarmTraj) or 4*n_agents (Quadcopter) */
 int nocf_ctrl_dim(const NocfProb* prob, int32_t d);
 

@@ -41,7 +41,7 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
     if len(alph) < 6:
         raise ValueError("alph needs 6 entries")
     Phi._guard_no_autograd(x, "OCflow")
-    phi_st, keep1, ws = Phi._c_struct()
+    phi_st, keep1, ws = Phi._c_struct(n)
     prob_st, keep2 = prob._c_struct(x.device)
     dev = x.device
     persample = torch.empty(n, 7, dtype=torch.float32, device=dev)

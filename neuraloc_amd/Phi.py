@@ -66,8 +66,9 @@ class Phi(nn.Module):
         self._ws = None
 
     # ---- boundary helpers -------------------------------------------------------------
-    def _c_struct(self):
-        """(NocfPhi, keep-alive list, workspace tensor) for the current parameters."""
+    def _c_struct(self, n=0):
+        """(NocfPhi, keep-alive list, workspace tensor) for the current parameters; n = rollout batch size
+        (0: a Phi-only call) sizes the optional activation-exchange area."""
         dev = self.A.device
         lay = self.N.layers
         keep = []
@@ -92,7 +93,7 @@ class Phi(nn.Module):
         st.A = dv(self.A, "A")
         st.cw = dv(self.c.weight, "c.weight")
         st.cb = float(self.c.bias.detach().cpu().item())
-        nbytes = _lib.lib().nocf_workspace_bytes(self.d, self.m, self.nTh)
+        nbytes = _lib.lib().nocf_rollout_workspace_bytes(self.d, self.m, self.nTh, int(n))
         if nbytes == 0:
             raise RuntimeError("nocf_workspace_bytes: unsupported (d, m, nTh)")
         if self._ws is None or self._ws.device != dev or self._ws.numel() < nbytes:

@@ -48,6 +48,8 @@ def lib():
     L.nocf_version.restype = C.c_int
     L.nocf_workspace_bytes.restype = C.c_size_t
     L.nocf_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.nocf_rollout_workspace_bytes.restype = C.c_size_t
+    L.nocf_rollout_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
     L.nocf_ctrl_dim.restype = C.c_int
     L.nocf_ctrl_dim.argtypes = [C.POINTER(NocfProb), C.c_int32]
     L.nocf_rollout_f32.restype = C.c_int

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -965,7 +966,8 @@ __global__ void __launch_bounds__(512) prob_kernel(DevPlan pl, DevProb pb, const
 }
 
 // deterministic reduction of the per-sample table: 7 column sums (fp64 accumulation, fixed order) + n
-__global__ void __launch_bounds__(256) cost_sum_kernel(const float* __restrict__ tab, long n, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) cost_sum_kernel(const float* __restrict__ tab, long n, float* __restrict__ out,
+                                                       const unsigned* __restrict__ err) {
     __shared__ double sh[256 * 7];
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (long row = threadIdx.x; row < n; row += 256)
@@ -978,7 +980,8 @@ __global__ void __launch_bounds__(256) cost_sum_kernel(const float* __restrict__
         __syncthreads();
     }
     if (threadIdx.x < 7) out[threadIdx.x] = (float)sh[threadIdx.x];
-    if (threadIdx.x == 7) out[7] = (float)n;
+    // a timed-out exchange in the group kernel must not pass as a result: poison the count -> every mean is NaN
+    if (threadIdx.x == 7) out[7] = (err && *err) ? __int_as_float(0x7fc00000) : (float)n;
 }
 
 __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* __restrict__ b, int K, float* __restrict__ out) {
@@ -986,6 +989,13 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K; ++k) acc = mfma4(a[(lane & 3) * K + k], b[k * 64 + lane], acc);
     for (int q = 0; q < 4; ++q) out[q * 64 + lane] = acc[q];
+}
+
+#include "nocf_group.inc"
+
+__global__ void store_group_plan_kernel(GroupPlan gp, float* ws) {
+    if (threadIdx.x < sizeof(GroupPlan) / 4)
+        reinterpret_cast<unsigned*>(ws + gp.pp.oPlan)[threadIdx.x] = reinterpret_cast<const unsigned*>(&gp)[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1087,6 +1097,67 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
     return 0;
 }
 
+// Group (weight-sliced) plan: returns 0 and fills *out when the shape qualifies, else an NOCF_E_* code.
+static int make_group_plan(const DevPlan& base, int n_agents, int kind /* NOCF_PROB_* or -1 */, long n, GroupPlan* out) {
+    GroupPlan gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.pp = base;
+    DevPlan& pl = gp.pp;
+    const int G = base.MB;
+    if (!(G == 2 || G == 4 || G == 8 || G == 16) || base.DB > 4) return NOCF_E_SHAPE;
+    gp.G = G; gp.OWN = GK_TG / G; gp.L = base.nTh - 1;
+    pl.T = gp.OWN; pl.nwaves = 4;
+    gp.LDg = rup(std::max(base.KQm * 4, base.m), 64) + 4;
+    gp.LDy = 68;
+    const int L = gp.L, TG = GK_TG, OWN = gp.OWN;
+    const int npairs = (n_agents * (n_agents - 1)) / 2;
+    int l = 0;
+    auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
+    gp.lR1 = take(std::max(TG * base.LDs, 4 * TG * 64));
+    gp.lUV = take(std::max(TG * gp.LDg, 4 * TG * 64));      // also hosts the opening phase's partial slots
+    gp.lGT = take(L * TG * 64);
+    gp.lAVo = take(TG * 64);
+    gp.lUo = take((L > 1 ? 2 : 1) * TG * 64);
+    gp.lYo = take(TG * gp.LDy + 32);
+    gp.lVO = take((L + 2) * 64);
+    gp.lCW = take(base.DB * 64);
+    pl.lSB = take(OWN * base.LDs);
+    pl.lG = take(OWN * base.GLD);
+    pl.lZQ = take(OWN * ZQLD);
+    pl.lZ0 = take(OWN * base.ZLD); pl.lZA = take(OWN * base.ZLD); pl.lDZ = take(OWN * base.ZLD);
+    pl.lRED = take(std::max(OWN, 4) * 4);
+    pl.lSC = take(OWN * std::max(1, n_agents) + 8);
+    pl.lPHI = take(OWN);
+    const bool maybe_quad = (kind < 0 || kind == NOCF_PROB_QUADCOPTER);
+    pl.lTRIG = take(maybe_quad ? OWN * std::max(1, n_agents) * 6 : 4);
+    pl.lPT = take((kind != NOCF_PROB_QUADCOPTER && n_agents > 2) ? (npairs + 1) / 2 + 1 : 4);
+    take(64);
+    pl.ldsFloats = l;
+    if ((size_t)l * 4 > 80 * 1024) return NOCF_E_LDS;          // two workgroups per CU must fit
+    // exchange regions and flags behind the plan record
+    gp.ngroups = (int)((n + TG - 1) / TG);
+    gp.nKinds = 2 * L + 2;
+    gp.SLDx = base.KQ1 * 4;
+    int x = 0;
+    auto xt = [&](int nfl) { int o = x; x += rup(nfl, 64); return o; };
+    gp.xS = xt(TG * gp.SLDx);
+    gp.xHstride = rup(TG * base.m, 64);
+    gp.xH = xt(2 * L * gp.xHstride);
+    gp.xG = xt(G * TG * base.GLD);
+    gp.xP = xt(G * TG);
+    gp.xStride = x;
+    long o = base.oPlan + (long)rup((int)(sizeof(GroupPlan) / 4), 64);
+    gp.oFlags = o; o += rup(gp.ngroups * gp.nKinds * G, 64);
+    gp.oErr = o; o += 64;
+    gp.oX = o;
+    *out = gp;
+    return 0;
+}
+
+static size_t group_ws_bytes(const GroupPlan& gp) {
+    return (size_t)(gp.oX + (long)gp.ngroups * gp.xStride) * sizeof(float);
+}
+
 static size_t plan_ws_bytes(const DevPlan& pl) {
     return (size_t)pl.oPlan * sizeof(float) + ((sizeof(DevPlan) + 15) / 16) * 16;
 }
@@ -1186,6 +1257,16 @@ size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh) {
     return plan_ws_bytes(pl);
 }
 
+size_t nocf_rollout_workspace_bytes(int32_t d, int32_t m, int32_t nTh, int64_t n) {
+    DevPlan pl;
+    const int r = std::min(10, d + 1);
+    if (make_plan(d, m, nTh, r, 1, &pl) != 0) return 0;
+    size_t b = plan_ws_bytes(pl);
+    GroupPlan gp;
+    if (n > 0 && make_group_plan(pl, 1, NOCF_PROB_QUADCOPTER, n, &gp) == 0) b = std::max(b, group_ws_bytes(gp));   // LDS-lightest view; sizes of the exchange area do not depend on the problem
+    return b;
+}
+
 int nocf_ctrl_dim(const NocfProb* prob, int32_t d) {
     if (!prob) return NOCF_E_NULL;
     return prob->kind == NOCF_PROB_QUADCOPTER ? 4 * prob->n_agents : d;
@@ -1221,28 +1302,62 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull;
     ra.cdim = nocf_ctrl_dim(prob, phi->d);
     ra.stamps = g_stamp_buf;
-    const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
-    const int grid = (int)((n + pl.T - 1) / pl.T);
-    const int block = pl.nwaves * 64;
     hipError_t e;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (g_prof_on) {
-        if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
-        (void)hipEventRecord(ev0, st);
+    const unsigned* errp = nullptr;
+    // weight-sliced group kernel: when the hidden width spans 2..16 column blocks, the caller's workspace has
+    // room for the exchange buffers and every workgroup of the grid can be resident at once (2 per CU)
+    GroupPlan gp;
+    bool use_group = env_int("NOCF_GROUP", 0) != 0 && make_group_plan(pl, pb.nAgents, pb.kind, n, &gp) == 0 &&
+                     workspace_bytes >= group_ws_bytes(gp);
+    if (use_group) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) use_group = false;
+        else if ((long)gp.ngroups * gp.G > 2L * cus) use_group = false;
     }
-    switch (pl.T / 4) {
-        case 1: e = set_lds(rollout_kernel<1>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(rollout_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
-        case 2: e = set_lds(rollout_kernel<2>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(rollout_kernel<2>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
-        default: e = set_lds(rollout_kernel<4>, ldsBytes); if (e) return (int)e;
-                hipLaunchKernelGGL(rollout_kernel<4>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
+    if (use_group) {
+        gp.pp.cb = phi->cb;
+        hipLaunchKernelGGL(store_group_plan_kernel, dim3(1), dim3(256), 0, st, gp, ws);
+        const size_t zbytes = (size_t)(gp.oX - gp.oFlags) * 4;                 // flags + error word
+        e = hipMemsetAsync(ws + gp.oFlags, 0, zbytes, st);
+        if (e) return (int)e;
+        const size_t ldsBytes = (size_t)gp.pp.ldsFloats * 4;
+        e = set_lds(rollout_group_kernel, ldsBytes); if (e) return (int)e;
+        if (env_int("NOCF_DEBUG", 0)) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_group_kernel, 256, ldsBytes);
+            fprintf(stderr, "[nocf] group kernel: %d groups x %d members, LDS %zu B/workgroup, occupancy API %d workgroups/CU\n",
+                    gp.ngroups, gp.G, ldsBytes, nb);
+        }
+        if (g_prof_on) {
+            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+            (void)hipEventRecord(ev0, st);
+        }
+        hipLaunchKernelGGL(rollout_group_kernel, dim3(gp.ngroups * gp.G), dim3(256), ldsBytes, st,
+                           reinterpret_cast<const GroupPlan*>(ws + gp.pp.oPlan), pb, ws, ra);
+        errp = reinterpret_cast<const unsigned*>(ws) + gp.oErr;
+    } else {
+        const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
+        const int grid = (int)((n + pl.T - 1) / pl.T);
+        const int block = pl.nwaves * 64;
+        if (g_prof_on) {
+            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+            (void)hipEventRecord(ev0, st);
+        }
+        switch (pl.T / 4) {
+            case 1: e = set_lds(rollout_kernel<1>, ldsBytes); if (e) return (int)e;
+                    hipLaunchKernelGGL(rollout_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
+            case 2: e = set_lds(rollout_kernel<2>, ldsBytes); if (e) return (int)e;
+                    hipLaunchKernelGGL(rollout_kernel<2>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
+            default: e = set_lds(rollout_kernel<4>, ldsBytes); if (e) return (int)e;
+                    hipLaunchKernelGGL(rollout_kernel<4>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
+        }
     }
     e = hipGetLastError();
     if (e) return (int)e;
     if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
     if (cost_sums) {
-        hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums);
+        hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
         e = hipGetLastError();
         if (e) return (int)e;
     }
