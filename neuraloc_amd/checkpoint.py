@@ -1,0 +1,33 @@
+"""Checkpoint I/O compatible with the reference.
+
+The reference saves `{'args': argparse.Namespace, 'state_dict': net.state_dict()}` whenever validation improves
+(trainOC.py:199-207) and rebuilds Phi from `args.m`, `args.nTh`, `args.alph`, `args.data` (evalOC.py:51-64).
+State-dict keys are identical here, so its .pth files load unchanged and files written here load there."""
+import argparse
+
+import torch
+
+from .Phi import Phi
+from .initProb import initProb
+
+
+def load_checkpoint(path, device="cuda:0", n_train=None, n_val=None, var0=None):
+    """-> (net, prob, x0, x0v, xInit, args); `args` is the pickled Namespace (weights_only=False is required
+    for the reference's files on torch >= 2.6 because they pickle argparse.Namespace)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    a = ck["args"]
+    alph = [float(v) for v in a.alph]
+    dev = torch.device(device)
+    cvt = lambda t: t.to(torch.float32).to(dev)           # noqa: E731
+    prob, x0, x0v, xInit = initProb(a.data, n_train or getattr(a, "n_train", 1024), n_val or getattr(a, "n_train", 1024),
+                                    var0=var0 if var0 is not None else getattr(a, "var0", 1.0), alph=alph, cvt=cvt)
+    net = Phi(nTh=a.nTh, m=a.m, d=x0.shape[1], alph=alph)
+    net.load_state_dict(ck["state_dict"])
+    return net.to(torch.float32).to(dev), prob, x0, x0v, xInit, a
+
+
+def save_checkpoint(path, net, args):
+    """same dict layout as trainOC.py:199-207; `args` may be a Namespace or a dict with data/m/nTh/alph"""
+    if isinstance(args, dict):
+        args = argparse.Namespace(**args)
+    torch.save({"args": args, "state_dict": {k: v.detach().cpu() for k, v in net.state_dict().items()}}, path)

@@ -582,15 +582,49 @@ __device__ __forceinline__ bool want_W(const DevProb& pb) {
     return (pb.kind == NOCF_PROB_QUADCOPTER) ? (pb.alphW > 0.0) : (pb.alphW != 0.0);
 }
 
-// pair table for the N>2 interaction sum: entry p = (i << 8) | j, i < j   (built once per launch)
+// pair table for the N>2 interaction sum: entry p = (ad*i << 16) | ad*j for i < j, i.e. the two agents' float
+// offsets inside a state row, so the hot loop needs no multiply   (built once per launch)
 __device__ void build_pair_table(const Ctx& c, const DevPlan& pl, const DevProb& pb) {
     if (pb.kind == NOCF_PROB_QUADCOPTER || pb.nAgents <= 2 || !want_W(pb)) return;
-    unsigned short* PT = reinterpret_cast<unsigned short*>(lds + pl.lPT);
-    const int N = pb.nAgents;
+    unsigned* PT = reinterpret_cast<unsigned*>(lds + pl.lPT);
+    const int N = pb.nAgents, ad = pb.agentDim;
     for (int idx = c.tid; idx < N * N; idx += c.nthreads) {
         const int i = idx / N, j = idx - i * N;
-        if (i < j) PT[i * N - (i * (i + 1)) / 2 + (j - i - 1)] = (unsigned short)((i << 8) | j);
+        if (i < j) PT[i * N - (i * (i + 1)) / 2 + (j - i - 1)] = ((unsigned)(i * ad) << 16) | (unsigned)(j * ad);
     }
+}
+
+// squared distances of 4 agent pairs per trip (all LDS reads issued before the first use), PD = 2 or 3
+template <int PD>
+__device__ __forceinline__ float pair_sum(const float* __restrict__ x, const unsigned* __restrict__ PT, int npairs,
+                                          int j0, int Gsz, float thr, float thr2, float den) {
+    float w = 0.f;
+    for (int q0 = j0; q0 < npairs; q0 += 4 * Gsz) {
+        unsigned ij[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = q0 + u * Gsz; ij[u] = PT[q < npairs ? q : 0]; }
+        float s2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* xi = x + (ij[u] >> 16);
+            const float* xj = x + (ij[u] & 0xffffu);
+            float a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < PD; ++k) { const float e = xi[k] - xj[k]; a2 += e * e; }
+            s2[u] = (q0 + u * Gsz < npairs) ? a2 : 3.0e38f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s2[u] < thr2) {                                  // cheap reject; the exact test follows
+                const float dist = sqrtf(s2[u]);
+                if (dist < thr) {
+                    const float e = expf(-(dist * dist) / den);
+                    if (e != 1.f) w += e;                        // the reference drops entries equal to 1.
+                }
+            }
+        }
+    }
+    return w;
 }
 
 // Phase 1 (all threads): per-sample partial sums -> RED (ends with a barrier).
@@ -629,33 +663,11 @@ __device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb)
         } else if (pb.kind != NOCF_PROB_QUADCOPTER) {
             const double fac = pb.training ? (pb.kind == NOCF_PROB_SWARMTRAJ ? 3.2 : 2.2) : 2.0;
             const float thr = (float)(fac * pb.r);
-            const float thr2 = thr * thr * 1.000002f;            // cheap reject; the exact test follows
-            const unsigned short* PT = reinterpret_cast<const unsigned short*>(Lm + pl.lPT);
+            const float thr2 = thr * thr * 1.000002f;
+            const unsigned* PT = reinterpret_cast<const unsigned*>(Lm + pl.lPT);
             const int npairs = (N * (N - 1)) / 2;
-            // four pairs per trip: the distance tests are independent, only rare close pairs reach the exp
-            for (int q0 = j0; q0 < npairs; q0 += 4 * Gsz) {
-                float s2[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = q0 + u * Gsz;
-                    const unsigned ij = PT[q < npairs ? q : 0];
-                    const float* xi = x + ad * (ij >> 8);
-                    const float* xj = x + ad * (ij & 255u);
-                    float acc2 = 0.f;
-                    for (int k = 0; k < pd; ++k) { const float e = xi[k] - xj[k]; acc2 += e * e; }
-                    s2[u] = (q < npairs) ? acc2 : 3.0e38f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (s2[u] < thr2) {
-                        const float dist = sqrtf(s2[u]);
-                        if (dist < thr) {
-                            const float e = expf(-(dist * dist) / den);
-                            if (e != 1.f) v[2] += e;             // the reference drops entries equal to 1.
-                        }
-                    }
-                }
-            }
+            v[2] = (pd == 3) ? pair_sum<3>(x, PT, npairs, j0, Gsz, thr, thr2, den)
+                             : pair_sum<2>(x, PT, npairs, j0, Gsz, thr, thr2, den);
         }
     }
     if (pb.kind == NOCF_PROB_QUADCOPTER && j0 < 3 * N) {       // sin/cos of (psi, theta, phi) per agent
@@ -837,9 +849,8 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
                     if (last && ra.zFull && row0 + t < ra.n)
                         ra.zFull[((long)(k + 1) * ra.n + row0 + t) * (d + 4) + i] = xs;
                 };
-                if (!quad) {
-                    for (int t = 0; t < T; ++t)
-                        for (int i = c.tid; i < d; i += c.nthreads) rk(t, i, -G[t * pl.GLD + i]);   // dx = -grad_p H = -p
+                if (!quad) {                                    // dx = -grad_p H = -p, all T*d components in one flat sweep
+                    for (int j = c.tid; j < T * d; j += c.nthreads) { const int t = j / d, i = j - t * d; rk(t, i, -G[t * pl.GLD + i]); }
                 }
                 if (c.tid < T) {
                     const int s = c.tid;
@@ -1084,7 +1095,7 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
         pl.lSC = take(T * std::max(1, n_agents) + 8);
         pl.lPHI = take(T);
         pl.lTRIG = take(T * std::max(1, n_agents) * 6);
-        pl.lPT = take((npairs + 1) / 2 + 1);
+        pl.lPT = take(npairs + 1);
         pl.nVEC = (int)(pl.oPlan - pl.ob0);
         pl.lVEC = take(pl.nVEC);
         take(64);                                   // slack: the activation ring's last prefetch reads 32 floats past a row
@@ -1130,7 +1141,7 @@ static int make_group_plan(const DevPlan& base, int n_agents, int kind /* NOCF_P
     pl.lPHI = take(OWN);
     const bool maybe_quad = (kind < 0 || kind == NOCF_PROB_QUADCOPTER);
     pl.lTRIG = take(maybe_quad ? OWN * std::max(1, n_agents) * 6 : 4);
-    pl.lPT = take((kind != NOCF_PROB_QUADCOPTER && n_agents > 2) ? (npairs + 1) / 2 + 1 : 4);
+    pl.lPT = take((kind != NOCF_PROB_QUADCOPTER && n_agents > 2) ? npairs + 1 : 4);
     take(64);
     pl.ldsFloats = l;
     if ((size_t)l * 4 > 80 * 1024) return NOCF_E_LDS;          // two workgroups per CU must fit

@@ -30,8 +30,8 @@ def test_every_declared_symbol_is_exported(L):
 
 
 def test_workspace_sizes(L):
-    # swarm50: opening 8*48*64 + closing 3*128*64 + (forward, backward) 2*8*128*64 float4 images + padded vectors
-    n4 = 8 * 48 * 64 + 3 * 128 * 64 + 2 * 8 * 128 * 64
+    # swarm50: opening 8*40*64 + closing 3*128*64 + (forward, backward) 2*8*128*64 float4 images + padded vectors
+    n4 = 8 * 40 * 64 + 3 * 128 * 64 + 2 * 8 * 128 * 64
     nv = 8 * 64 + 8 * 64 + 8 * 64 + 3 * 64 + 10 * 151 + 2          # ... + the copy of A (padded to 4 floats)
     got = L.nocf_workspace_bytes(150, 512, 2)
     assert (n4 * 4 + nv) * 4 < got <= (n4 * 4 + nv) * 4 + 1024          # + the plan record
@@ -76,3 +76,19 @@ def test_state_dict_contract():
     assert net.A.shape == (5, 5) and float(net.w.weight.min()) == 1.0 and float(net.c.weight.abs().max()) == 0.0
     with pytest.raises(ValueError):
         na.Phi(1, 8, 4)
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    """{'args': Namespace, 'state_dict'} files, same keys as the reference writes"""
+    import argparse
+    import neuraloc_amd as na
+    from neuraloc_amd.checkpoint import save_checkpoint
+    net = na.Phi(2, 16, 4, alph=[300.0, 1e6, 1e5, 1.0, 1.0, 3.0])
+    path = tmp_path / "swap2_checkpt.pth"
+    save_checkpoint(str(path), net, argparse.Namespace(data="swap2", m=16, nTh=2, alph=net.alph, n_train=8, var0=1.0))
+    ck = torch.load(str(path), map_location="cpu", weights_only=False)
+    assert set(ck) == {"args", "state_dict"} and ck["args"].data == "swap2"
+    assert list(ck["state_dict"]) == list(net.state_dict())
+    net2 = na.Phi(2, 16, 4)
+    net2.load_state_dict(ck["state_dict"])
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))

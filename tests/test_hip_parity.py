@@ -271,3 +271,27 @@ def test_group_kernel_matches_reference_golden(name, tag, monkeypatch):
     cw = torch.from_numpy(g[tag + "/ctrlFull"])
     bad, worst = count_off(cF.cpu(), cw, 1e-4, 1e-4 * float(cw.abs().max()) + 1e-5)
     assert bad == 0, f"{name} {tag}: {bad} control entries off (worst {worst:g})"
+
+
+def test_shock_rollout_matches_two_reference_style_segments(golden_pretrained):
+    """the two-segment shocked rollout (src/plotter.py:815-824) against the oracle"""
+    from neuraloc_amd.shock import shock_rollout
+    g = golden_pretrained
+    net = make_net(g, DEV)
+    prob = make_prob(g, DEV, training=False)
+    P, S = make_oracle(g, training=False)
+    x = g.t("x")[:6]
+    d, nt, t_s = g.meta["d"], 20, 0.1
+    shock = 0.05 * torch.arange(1, d + 1, dtype=torch.float32).reshape(1, -1) / d
+    with torch.no_grad():
+        res = shock_rollout(x.to(DEV), net, prob, nt, t_s, shock.to(DEV))
+        nS = int(t_s * nt)
+        z1, _ = orc.rollout(x, P, S, [0.0, t_s], nS, "rk4", g.meta["alph"], intermediates=True)
+        xs = z1[:, :d, -1] + shock
+        z2, _ = orc.rollout(xs, P, S, [t_s, 1.0], 1 + nt - nS, "rk4", g.meta["alph"], intermediates=True)
+    want = torch.cat((z1[:, :d, :], z2[:, :d, :]), dim=2)
+    assert res["nShock"] == nS and res["traj"].shape == want.shape
+    bad, worst = count_off(res["traj"].cpu(), want, 1e-5, 1e-4)
+    assert bad == 0, f"{g.name}: {bad} shocked-trajectory entries off (worst {worst:g})"
+    with pytest.raises(ValueError):
+        shock_rollout(x.to(DEV), net, prob, nt, 0.01, shock.to(DEV))      # nShock = 0: the reference divides by zero
