@@ -295,3 +295,48 @@ def test_shock_rollout_matches_two_reference_style_segments(golden_pretrained):
     assert bad == 0, f"{g.name}: {bad} shocked-trajectory entries off (worst {worst:g})"
     with pytest.raises(ValueError):
         shock_rollout(x.to(DEV), net, prob, nt, 0.01, shock.to(DEV))      # nShock = 0: the reference divides by zero
+
+
+# ---- every problem initProb knows (15 names), small deterministic nets, both modes: HIP vs the oracle
+def _synth_state_dict(nTh, m, d, seed):
+    import neuraloc_amd as na_
+    net = na_.Phi(nTh=nTh, m=m, d=d)
+    sd = net.state_dict()
+    for j, (k, v) in enumerate(sd.items()):
+        n = v.numel()
+        i = torch.arange(n, dtype=torch.float64)
+        fan = v.shape[-1] if v.dim() > 1 else 4
+        sd[k] = (0.8 / fan ** 0.5 * torch.sin(0.37 * i + 0.11 * (i % 7) + 0.3 * j + seed)).reshape(v.shape).float()
+    sd["w.weight"] = sd["w.weight"] + 1.0
+    return sd
+
+
+@pytest.mark.parametrize("name", sorted(na.initProb.__globals__["PROBLEM_NAMES"]))
+@pytest.mark.parametrize("training", [False, True])
+def test_every_initprob_problem_against_oracle(name, training):
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(7)
+    prob, x0, _, xInit = na.initProb(name, 24, 24, 0.5, alph, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    d = x0.shape[1]
+    nTh, m = (3, 40) if d > 30 else (2, 24)
+    sd = _synth_state_dict(nTh, m, d, seed=len(name))
+    net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    P = orc.PhiParams.from_state_dict(sd)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    nt = 6
+    with torch.no_grad():
+        _, csn = na.OCflow(x0, net, prob, [0.0, 1.0], nt, "rk4", alph, noMean=True)
+        zF, cF = na.OCflow(x0[:5], net, prob, [0.0, 1.0], nt, "rk4", alph, intermediates=True)
+        want = orc.persample_table(x0.cpu(), P, S, [0.0, 1.0], nt, "rk4", alph)
+        zW, cW = orc.rollout(x0[:5].cpu(), P, S, [0.0, 1.0], nt, "rk4", alph, intermediates=True)
+    tab = torch.cat(csn, 1).cpu()
+    off = (tab.double() - want.double()).abs() > 1e-3 + 1e-3 * want.double().abs()
+    assert int(off.any(dim=1).sum()) <= 2, f"{name}: {int(off.any(dim=1).sum())} samples off"
+    bad, worst = count_off(zF.cpu()[:, :d], zW[:, :d], 1e-5, 1e-4)
+    assert bad == 0, f"{name}: {bad} state entries off (worst {worst:g})"
+    bad, worst = count_off(cF.cpu(), cW, 1e-4, 1e-4 * float(cW.abs().max()) + 1e-5)
+    assert bad == 0, f"{name}: {bad} control entries off (worst {worst:g})"
