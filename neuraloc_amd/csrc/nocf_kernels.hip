@@ -1003,6 +1003,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 }
 
 #include "nocf_group.inc"
+#include "nocf_lane.inc"
 
 __global__ void store_group_plan_kernel(GroupPlan gp, float* ws) {
     if (threadIdx.x < sizeof(GroupPlan) / 4)
@@ -1304,9 +1305,6 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     if (workspace_bytes < plan_ws_bytes(pl)) return NOCF_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-    rc = pack_weights(pl, phi, ws, st);
-    if (rc) return rc;
-    const DevPlan* plp = reinterpret_cast<const DevPlan*>(ws + pl.oPlan);
     RollArgs ra;
     ra.x = x; ra.n = n; ra.t0 = t0; ra.t1 = t1; ra.h = (t1 - t0) / nt; ra.nt = nt; ra.stepper = stepper;
     ra.a0 = alph[0];
@@ -1316,6 +1314,37 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     hipError_t e;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const unsigned* errp = nullptr;
+    // small networks: one wave per sample, everything in registers (nocf_lane.inc); needs no packed images
+    const bool lane_ok = env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&
+                         pb.kind != NOCF_PROB_QUADCOPTER && pb.nAgents <= 16 && !g_stamp_buf;
+    if (lane_ok) {
+        LaneArgs la;
+        la.P = DevPhi{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw};
+        la.d = phi->d; la.m = phi->m; la.r = phi->r; la.nAg = pb.nAgents; la.cb = phi->cb;
+        const int grid = (int)((n + 3) / 4);
+        const int MPsel = phi->m <= 16 ? 16 : 32;
+        const int DPsel = phi->d + 1 <= 8 ? 8 : (phi->d + 1 <= 16 ? 16 : 32);
+        if (g_prof_on) {
+            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+            (void)hipEventRecord(ev0, st);
+        }
+#define NOCF_LANE_LAUNCH(MPV, DPV) hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV>), dim3(grid), dim3(256), 0, st, la, pb, ra)
+        if (MPsel == 16) { if (DPsel == 8) NOCF_LANE_LAUNCH(16, 8); else if (DPsel == 16) NOCF_LANE_LAUNCH(16, 16); else NOCF_LANE_LAUNCH(16, 32); }
+        else             { if (DPsel == 8) NOCF_LANE_LAUNCH(32, 8); else if (DPsel == 16) NOCF_LANE_LAUNCH(32, 16); else NOCF_LANE_LAUNCH(32, 32); }
+#undef NOCF_LANE_LAUNCH
+        e = hipGetLastError();
+        if (e) return (int)e;
+        if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
+        if (cost_sums) {
+            hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
+            e = hipGetLastError();
+            if (e) return (int)e;
+        }
+        return 0;
+    }
+    rc = pack_weights(pl, phi, ws, st);
+    if (rc) return rc;
+    const DevPlan* plp = reinterpret_cast<const DevPlan*>(ws + pl.oPlan);
     // weight-sliced group kernel: when the hidden width spans 2..16 column blocks, the caller's workspace has
     // room for the exchange buffers and every workgroup of the grid can be resident at once (2 per CU)
     GroupPlan gp;
