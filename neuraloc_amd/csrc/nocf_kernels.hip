@@ -852,15 +852,30 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
                 if (!quad) {                                    // dx = -grad_p H = -p, all T*d components in one flat sweep
                     for (int j = c.tid; j < T * d; j += c.nthreads) { const int t = j / d, i = j - t * d; rk(t, i, -G[t * pl.GLD + i]); }
                 }
-                if (c.tid < T) {
-                    const int s = c.tid;
-                    const Costs cs = physics_finish(c, pl, pb, s);
-                    if (quad) for (int i = 0; i < d; ++i) rk(s, i, DZ[s * ZLD + i]);
-                    rk(s, d, cs.L);
-                    rk(s, d + 1, fabsf(G[s * pl.GLD + d] - cs.H));
-                    rk(s, d + 2, cs.Q);
-                    rk(s, d + 3, cs.W);
-                    SB[s * pl.LDs + d] = (float)tnext;
+                if (!quad) {
+                    if (c.tid < T) {
+                        const int s = c.tid;
+                        const Costs cs = physics_finish(c, pl, pb, s);
+                        rk(s, d, cs.L);
+                        rk(s, d + 1, fabsf(G[s * pl.GLD + d] - cs.H));
+                        rk(s, d + 2, cs.Q);
+                        rk(s, d + 3, cs.W);
+                        SB[s * pl.LDs + d] = (float)tnext;
+                    }
+                } else {
+                    // quadcopter: one thread per sample forms the whole right-hand side (sequential agent loop of
+                    // the reference), then every thread takes part in the RK update of the T*(d+4) components
+                    if (c.tid < T) {
+                        const int s = c.tid;
+                        const Costs cs = physics_finish(c, pl, pb, s);
+                        DZ[s * ZLD + d] = cs.L;
+                        DZ[s * ZLD + d + 1] = fabsf(G[s * pl.GLD + d] - cs.H);
+                        DZ[s * ZLD + d + 2] = cs.Q;
+                        DZ[s * ZLD + d + 3] = cs.W;
+                    }
+                    __syncthreads();
+                    for (int j = c.tid; j < T * (d + 4); j += c.nthreads) { const int t = j / (d + 4), i = j - t * (d + 4); rk(t, i, DZ[t * ZLD + i]); }
+                    if (c.tid < T) SB[c.tid * pl.LDs + d] = (float)tnext;
                 }
             } else {
                 if (quad && c.tid < T) (void)physics_finish(c, pl, pb, c.tid);     // thrusts for calcCtrls
