@@ -25,12 +25,14 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-sys.path.insert(0, REF)
-sys.path.insert(0, REPO)
+sys.path.insert(0, REF)           # ONLY the reference on the path while its `src` namespace package is imported:
+                                  # this repository's own `src/` shims (a regular package) would win otherwise
 
 from src.Phi import Phi as RefPhi                      # noqa: E402  (reference)
 from src.OCflow import OCflow as RefOCflow             # noqa: E402
 from src.initProb import initProb as ref_initProb      # noqa: E402
+
+sys.path.insert(1, REPO)          # now the repository (oracle/), behind the already-imported reference modules
 
 from oracle import ocflow_oracle as orc                # noqa: E402
 
