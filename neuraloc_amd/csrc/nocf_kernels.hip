@@ -257,20 +257,25 @@ __device__ __forceinline__ void ring_preload(const Ctx& c, Ring& rg, const Phase
 //           so no MFMA waits on an LDS read it has just issued.
 // Weights come through buffer loads (scalar byte offset + lane*16: no per-load 64-bit address
 // arithmetic); no branch sits between the loads, so the waits are counted vmcnt/lgkmcnt.
+template <int S> struct ActRing { static constexpr int AH = (S == 1) ? HALF : HALF / 2; };   // k-quads of activations kept ahead
+
 template <int S, bool RW, bool RA>
-__device__ __forceinline__ void ring_half(const Ctx& c, float4 (&buf)[HALF], float4 (&a)[S][HALF], f32x4 (&acc)[S][4],
-                                          int a_next /*float4 index*/, int ld /*floats*/, int voff, int w_next /*bytes*/) {
+__device__ __forceinline__ void ring_half(const Ctx& c, float4 (&buf)[HALF], float4 (&a)[S][ActRing<S>::AH], f32x4 (&acc)[S][4],
+                                          int a_cur /*float4 index of THIS half's quad 0, this lane's row*/, int ld /*floats*/,
+                                          int voff, int w_next /*bytes*/) {
+    constexpr int AH = ActRing<S>::AH;
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
         const float4 w = buf[i];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const float4 av = a[s][i];
+            const float4 av = a[s][i % AH];
             acc[s][0] = mfma4(av.x, w.x, acc[s][0]);
             acc[s][1] = mfma4(av.y, w.y, acc[s][1]);
             acc[s][2] = mfma4(av.z, w.z, acc[s][2]);
             acc[s][3] = mfma4(av.w, w.w, acc[s][3]);
-            if (RA) a[s][i] = reinterpret_cast<const float4*>(lds)[a_next + s * ld + i];      // float4 index: ds_read_b128
+            // quad i+AH of the stream (the next half when it runs past this one; RA says whether that half exists)
+            if (RA || i + AH < HALF) a[s][i % AH] = reinterpret_cast<const float4*>(lds)[a_cur + s * ld + i + AH];
         }
         if (RW) buf[i] = wload(c, voff, w_next + i * 1024);
     }
@@ -312,27 +317,27 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring
         const int voff = (cb * 64 + c.lane < ph.ncols) ? c.lane * 16 : WOOB;
         int wo = (int)((ph.img4 + ((long)cb * ph.KQ + (long)h0 * HALF) * 64) * 16);   // byte offset, wave-uniform
         int ao = (act_off + arow * ld) / 4 + h0 * HALF;                               // float4 index, per lane
-        float4 av[S][HALF];
+        float4 av[S][ActRing<S>::AH];
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int i = 0; i < HALF; ++i) av[s][i] = reinterpret_cast<const float4*>(lds)[ao + s * ld + i];
+            for (int i = 0; i < ActRing<S>::AH; ++i) av[s][i] = reinterpret_cast<const float4*>(lds)[ao + s * ld + i];
         // halves alternate between rg.A and rg.B; half h is refilled with half h+2 while it is consumed
         int h = 0;
         for (; h + 3 < nh; h += 2) {
-            ring_half<S, true, true>(c, rg.A, av, acc, ao + HALF, ld, voff, wo + 2 * HALF * 1024);
-            ring_half<S, true, true>(c, rg.B, av, acc, ao + 2 * HALF, ld, voff, wo + 3 * HALF * 1024);
+            ring_half<S, true, true>(c, rg.A, av, acc, ao, ld, voff, wo + 2 * HALF * 1024);
+            ring_half<S, true, true>(c, rg.B, av, acc, ao + HALF, ld, voff, wo + 3 * HALF * 1024);
             wo += 2 * HALF * 1024;
             ao += 2 * HALF;
         }
         const int rem = nh - h;                         // 1, 2 or 3 halves left
         if (rem == 3) {
-            ring_half<S, true, true>(c, rg.A, av, acc, ao + HALF, ld, voff, wo + 2 * HALF * 1024);
-            ring_half<S, false, true>(c, rg.B, av, acc, ao + 2 * HALF, ld, voff, wo);
-            ring_half<S, false, false>(c, rg.A, av, acc, ao, ld, voff, wo);
+            ring_half<S, true, true>(c, rg.A, av, acc, ao, ld, voff, wo + 2 * HALF * 1024);
+            ring_half<S, false, true>(c, rg.B, av, acc, ao + HALF, ld, voff, wo);
+            ring_half<S, false, false>(c, rg.A, av, acc, ao + 2 * HALF, ld, voff, wo);
         } else if (rem == 2) {
-            ring_half<S, false, true>(c, rg.A, av, acc, ao + HALF, ld, voff, wo);
-            ring_half<S, false, false>(c, rg.B, av, acc, ao, ld, voff, wo);
+            ring_half<S, false, true>(c, rg.A, av, acc, ao, ld, voff, wo);
+            ring_half<S, false, false>(c, rg.B, av, acc, ao + HALF, ld, voff, wo);
         } else if (rem == 1) {
             ring_half<S, false, false>(c, rg.A, av, acc, ao, ld, voff, wo);
         }

@@ -31,7 +31,19 @@ __global__ void __launch_bounds__(512) kern(const float4* __restrict__ img, floa
         }
         const float4* wp = img + (long)((wave + r) % nblk) * KQ * 64 + lane;
         const float* ap = ap0;
-        if (PAT == 0) {
+        if constexpr (PAT >= 16) {             // rolling window of PAT loads in flight, accumulate into dummy
+            constexpr int D = PAT >= 16 ? PAT : 16;
+            float4 w[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) w[i] = wp[i * 64];
+            for (int q = 0; q < KQ; q += D) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    dummy.x += w[i].x; dummy.y += w[i].y; dummy.z += w[i].z; dummy.w += w[i].w;
+                    if (q + D + i < KQ) w[i] = wp[(q + D + i) * 64];
+                }
+            }
+        } else if constexpr (PAT == 0) {
             float4 wc[8], wn[8];
             if (MODE & 1) { for (int i = 0; i < 8; ++i) wc[i] = wp[i * 64]; } else { for (int i = 0; i < 8; ++i) wc[i] = make_float4(1, 2, 3, 4); }
             for (int ch = 0; ch < KQ / 8; ++ch) {
@@ -115,6 +127,11 @@ int main() {
     run("loads + mfma + lds, burst S=2", kern<7, 0, 2>, img, out, 128, 512, 2, nblk);
     run("loads + mfma + lds, ring  S=2", kern<7, 1, 2>, img, out, 128, 512, 2, nblk);
     run("loads + mfma + lds, burst, 32 blocks(4MB)", kern<7, 0, 1>, img, out, 256, 512, 1, 32);
+    run("loads only, window 16", kern<1, 16, 1>, img, out, 256, 512, 1, nblk);
+    run("loads only, window 32", kern<1, 32, 1>, img, out, 256, 512, 1, nblk);
+    run("loads only, window 64", kern<1, 64, 1>, img, out, 256, 512, 1, nblk);
+    run("loads only, window 32, 4 waves", kern<1, 32, 1>, img, out, 256, 256, 1, nblk);
+    run("loads only, window 64, 4 waves", kern<1, 64, 1>, img, out, 256, 256, 1, nblk);
     run("loads only, burst, 1 WG", kern<1, 0, 1>, img, out, 1, 512, 1, nblk);
     run("loads only, burst, 32 WG", kern<1, 0, 1>, img, out, 32, 512, 1, nblk);
     run("loads only, burst, 128 WG", kern<1, 0, 1>, img, out, 128, 512, 1, nblk);
