@@ -79,7 +79,8 @@ def cpu_baseline(meta, sd, xtarget, x, nt, budget_s=25.0):
     P = orc.PhiParams.from_state_dict(sd)
     S = orc.ProbSpec(kind, xtarget, meta["obstacle"], meta["alph_Q"], meta["alph_W"], meta["r"], training=False)
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (1, 4, 8, 16, 32, 64, ncpu) if c <= ncpu})
+    # eager PyTorch collapses far beyond 64 threads on these shapes (256 threads: < 1 traj/s), so the probe stops at 64
+    cands = sorted({c for c in (1, 4, 8, 16, 32, 64, min(ncpu, 64)) if c <= ncpu})
     probe = {}
     with torch.no_grad():
         for th in cands:
@@ -124,8 +125,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("NOCF_BENCH_BACKEND", "nccl")      # "gloo": only to exercise this script where ranks share a GPU
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(1, ndev)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         dist = None
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
@@ -149,10 +156,14 @@ def main():
     x_cpu = make_states(meta, xInit, n, seed=200 + rank)
     x = x_cpu.to(dev)                                   # inputs resident in HBM before the timed region
 
+    host_reduce = world > 1 and os.environ.get("NOCF_BENCH_BACKEND", "nccl") != "nccl"
+
     def step():
         _, sums, _, _ = _launch(x, net, prob, [0.0, 1.0], nt, "rk4", alph, False)
-        if world > 1:
-            reduce_cost_sums(sums)
+        if host_reduce:                                  # gloo test mode: reduce on the host
+            sums = reduce_cost_sums(sums.cpu()).to(dev)
+        elif world > 1:
+            reduce_cost_sums(sums)                       # one RCCL all-reduce of 8 floats
         return costs_from_sums(sums, alph)
 
     L = _lib.lib()
@@ -175,7 +186,7 @@ def main():
         kms, nl = C.c_double(0.0), C.c_int32(0)
         L.nocf_profile_end(C.byref(kms), C.byref(nl))
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_reduce else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
