@@ -124,6 +124,35 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob,
                      float* zFull, float* ctrlFull,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Training: the pair below replaces `Jc = OCflow(...); Jc.backward()` of trainOC.py:172-173
+ * for nTh = 2 networks and the point-agent problems (Cross2D, SwarmTraj).
+ *
+ * nocf_rollout_record_f32 = nocf_rollout_f32 that also records the stage input s=[x,t] of every RK evaluation:
+ *   s_all  device [nt*nstage, n, d+1]   (nstage = 4 for rk4, 1 for rk1);  z_out is required.
+ *
+ * nocf_rollout_bwd_f32 runs the exact adjoint of the discrete scheme.  It does not reduce the parameter
+ * gradients itself: it streams, for every sample and evaluation, the vectors whose outer products they are,
+ *   rows = (nt*nstage + 2) * n        (the two extra blocks are the terminal grad-Phi and Phi terms)
+ *   Y, Ob, V, Ab, Qb, U0, Wb   device [rows, m]   (zero-initialised by the caller)
+ *   Gb, Sx                     device [rows, d+1] (zero-initialised by the caller)
+ *   PHIb                       device [n]         cotangent of Phi(x_T, t1);  lam0 device [n, d] = dJc/dx0 (nullable)
+ * and the caller contracts them with library GEMMs:
+ *   dK0 = Y'Gb + Ob'Sx   db0 = sum Ob   dK1 = V'Ab + Qb'U0   db1 = sum Qb   dw = sum Wb   dc.weight = sum Gb + sum PHIb s_T
+ *   dc.bias = sum PHIb   dM = Gb'Sx + 1/2 sum PHIb s_T s_T'   dA = A (dM + dM')
+ *   hs      device [nt] fp32 step sizes as the forward used them: (float)((tk+h)-tk), tk += h in double
+ *   inv_n   1 / (global batch size) -- the means of src/OCflow.py:80-86 run over all shards
+ */
+int nocf_rollout_record_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                            double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                            float* z_out, float* persample, float* cost_sums, float* s_all,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                         const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                         float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                         float* PHIb, float* lam0, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Phi.getGrad -- replaces src/Phi.py:99-138.  s: device [n, d+1] -> grad: device [n, d+1] */
 int nocf_phi_grad_f32(const NocfPhi* phi, const float* s, int64_t n, float* grad,
                       void* workspace, size_t workspace_bytes, void* stream);

@@ -86,6 +86,12 @@ def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0
                     like the reference: src/OCflow.py:66-76)
     :return: (Jc, cs)  or  (zFull, ctrlFull)
     """
+    if (torch.is_grad_enabled() and not intermediates and not noMean
+            and any(p.requires_grad for p in Phi.parameters())):
+        from .train import ocflow_train                 # trainOC.py:172-173: Jc.backward() -> hand-written adjoint
+        if int(nt) < 1:
+            raise ValueError("nt must be >= 1")
+        return ocflow_train(x, Phi, prob, tspan, nt, stepper, alph)
     persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates and not noMean)
     if noMean:
         cs = [persample[:, i:i + 1] for i in range(7)]

@@ -59,6 +59,8 @@ struct DevPlan {
     // LDS carve (float offsets)
     int lSB, lU0, lU1, lTH, lAV, lV0, lV1, lPART, lG, lZQ, lZ0, lZA, lDZ, lRED, lSC, lPHI, lTRIG, lPT;
     int lVEC, nVEC;                  // biases, w, c.weight and A, copied once per launch (ws floats [ob0, oPlan))
+    int bwd;                         // 1: training plan (keeps tanh of the last layer, adjoint arrays, see nocf_bwd.inc)
+    int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD;   // adjoint LDS arrays (bwd plans only)
     int ldsFloats;
 };
 
@@ -476,8 +478,10 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
                     lds[oUn + t * LD + col] = lds[oUc + t * LD + col] + hN * sg;
                 } else {
                     const float wj = wv[col];
-                    lds[pl.lV0 + t * LD + col] = tanh_fast(q) * wj;
+                    const float th = tanh_fast(q);
+                    lds[pl.lV0 + t * LD + col] = th * wj;
                     lds[oAV + t * LD + col] = wj;
+                    if (pl.bwd) lds[oTHi + t * LD + col] = th;         // the adjoint needs tanh(q) itself
                     if (need_value) lds[oUn + t * LD + col] = lds[oUc + t * LD + col] + hN * sigma_act(q);
                 }
             }
@@ -770,6 +774,7 @@ struct RollArgs {
     float a0;
     float* z_out; float* persample; float* zFull; float* ctrlFull; int cdim;
     unsigned long long* stamps;
+    float* sAll;                     // training: stage inputs s=[x,t] of every RK evaluation, [nt*nstage][n][d+1]
 };
 
 template <int S>
@@ -828,6 +833,13 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
             if (c.tid < T) SB[c.tid * pl.LDs + d] = (float)ra.t1;      // src/OCflow.py:62
         }
         for (int st = 0; st < (fin ? 1 : nsub); ++st) {
+            if (ra.sAll && !fin && st < nstage) {           // record the stage input for the adjoint sweep
+                float* dst = ra.sAll + ((long)(k * nstage + st) * ra.n) * (d + 1);
+                for (int j = c.tid; j < T * (d + 1); j += c.nthreads) {
+                    const int t = j / (d + 1), i = j - t * (d + 1);
+                    if (row0 + t < ra.n) dst[(row0 + t) * (d + 1) + i] = SB[t * pl.LDs + i];
+                }
+            }
             // the ring is not carried across evaluations: keeping 64 registers alive through the physics cost spills
             phi_eval<S>(c, pl, fin, rg, ring_ready, false);
             if (fin) break;
@@ -1024,6 +1036,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 
 #include "nocf_group.inc"
 #include "nocf_lane.inc"
+#include "nocf_bwd.inc"
 
 __global__ void store_group_plan_kernel(GroupPlan gp, float* ws) {
     if (threadIdx.x < sizeof(GroupPlan) / 4)
@@ -1055,12 +1068,12 @@ static int env_int(const char* name, int dflt) {
 }
 
 // fills the shape / image part of the plan; returns 0 or an NOCF_E_* code
-static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
+static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, int bwd = 0) {
     if (d < 1 || m < 1 || nTh < 2 || nTh > MAX_NTH || r < 1 || r > d + 1 || r > ZQLD) return NOCF_E_SHAPE;
     if (n_agents > 255) return NOCF_E_SHAPE;
     DevPlan pl;
     memset(&pl, 0, sizeof(pl));
-    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh;
+    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh; pl.bwd = bwd;
     pl.MB = cdiv(m, 64); pl.DB = cdiv(pl.D1, 64);
     pl.KQ1 = rup(cdiv(pl.D1, 4), HALF); pl.KQm = rup(cdiv(m, 4), HALF);
     // geometry: waves per workgroup and sample sub-tiles
@@ -1094,7 +1107,7 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
     const int T = pl.T;
     const int npairs = (n_agents * (n_agents - 1)) / 2;
     int l = 0;
-    for (int cap = MAX_SK; cap >= 1; cap >>= 1) {
+    for (int cap = bwd ? 4 : MAX_SK; cap >= 1; cap >>= 1) {
         pl.SK1 = choose_sk(pl.MB, pl.KQ1 / HALF, nw, cap);
         pl.SK6 = choose_sk(pl.DB, pl.KQm / HALF, nw, cap);
         pl.SKm = choose_sk(pl.MB, pl.KQm / HALF, nw, cap);
@@ -1106,19 +1119,25 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out) {
         auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
         pl.lSB = take(T * pl.LDs);
         pl.lU0 = take(T * pl.LD); pl.lU1 = take(T * pl.LD);
-        pl.lTH = take((nTh - 1) * T * pl.LD);
+        pl.lTH = take((nTh - 1 + (bwd ? 1 : 0)) * T * pl.LD);
         pl.lAV = take(T * pl.LD); pl.lV0 = take(T * pl.LD); pl.lV1 = take(T * pl.LD);
         pl.lPART = take(partFloats);
         pl.lG = take(T * pl.GLD);
         pl.lZQ = take(T * ZQLD);
         pl.lZ0 = take(T * pl.ZLD); pl.lZA = take(T * pl.ZLD); pl.lDZ = take(T * pl.ZLD);
         pl.lRED = take(std::max(T, nw) * 4);
-        pl.lSC = take(T * std::max(1, n_agents) + 8);
+        pl.lSC = take(std::max(T * std::max(1, n_agents) + 8, T * 4 + 8));
         pl.lPHI = take(T);
         pl.lTRIG = take(T * std::max(1, n_agents) * 6);
         pl.lPT = take(npairs + 1);
         pl.nVEC = (int)(pl.oPlan - pl.ob0);
         pl.lVEC = take(pl.nVEC);
+        if (bwd) {
+            pl.lGB = take(T * pl.LDs);
+            pl.lAB = take(T * pl.LD); pl.lT0B = take(T * pl.LD); pl.lQB = take(T * pl.LD); pl.lOB = take(T * pl.LD);
+            pl.lSBAR = take(T * pl.GLD); pl.lZQB = take(T * ZQLD);
+            pl.lLAM = take(T * pl.ZLD); pl.lXS = take(T * pl.ZLD); pl.lXP = take(T * pl.ZLD); pl.lXD = take(T * pl.ZLD);
+        }
         take(64);                                   // slack: the activation ring's last prefetch reads 32 floats past a row
         if ((size_t)l * 4 <= 160 * 1024) break;
     }
@@ -1304,10 +1323,10 @@ int nocf_ctrl_dim(const NocfProb* prob, int32_t d) {
     return prob->kind == NOCF_PROB_QUADCOPTER ? 4 * prob->n_agents : d;
 }
 
-int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
-                     double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
-                     float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                        double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                        float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
+                        void* workspace, size_t workspace_bytes, void* stream, float* s_all) {
     int rc = check_phi(phi);
     if (rc) return rc;
     if (!x || !alph || !workspace) return NOCF_E_NULL;
@@ -1331,11 +1350,12 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull;
     ra.cdim = nocf_ctrl_dim(prob, phi->d);
     ra.stamps = g_stamp_buf;
+    ra.sAll = s_all;
     hipError_t e;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const unsigned* errp = nullptr;
     // small networks: one wave per sample, everything in registers (nocf_lane.inc); needs no packed images
-    const bool lane_ok = env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&
+    const bool lane_ok = !s_all && env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&
                          pb.kind != NOCF_PROB_QUADCOPTER && pb.nAgents <= 16 && !g_stamp_buf;
     if (lane_ok) {
         LaneArgs la;
@@ -1368,7 +1388,7 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
     // weight-sliced group kernel: when the hidden width spans 2..16 column blocks, the caller's workspace has
     // room for the exchange buffers and every workgroup of the grid can be resident at once (2 per CU)
     GroupPlan gp;
-    bool use_group = env_int("NOCF_GROUP", 0) != 0 && make_group_plan(pl, pb.nAgents, pb.kind, n, &gp) == 0 &&
+    bool use_group = !s_all && env_int("NOCF_GROUP", 0) != 0 && make_group_plan(pl, pb.nAgents, pb.kind, n, &gp) == 0 &&
                      workspace_bytes >= group_ws_bytes(gp);
     if (use_group) {
         int dev = 0, cus = 0;
@@ -1422,6 +1442,61 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
         if (e) return (int)e;
     }
     return 0;
+}
+
+int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                     double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                     float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, zFull, ctrlFull,
+                        workspace, workspace_bytes, stream, nullptr);
+}
+
+int nocf_rollout_record_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                            double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                            float* z_out, float* persample, float* cost_sums, float* s_all,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!s_all || !z_out) return NOCF_E_NULL;
+    return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, nullptr, nullptr,
+                        workspace, workspace_bytes, stream, s_all);
+}
+
+int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                         const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                         float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                         float* PHIb, float* lam0, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_phi(phi);
+    if (rc) return rc;
+    if (!alph || !s_all || !z_final || !hs || !Y || !Ob || !V || !Ab || !Qb || !U0 || !Wb || !Gb || !Sx || !PHIb || !workspace)
+        return NOCF_E_NULL;
+    if (n < 1 || nt < 1 || phi->nTh != 2) return NOCF_E_SHAPE;        // deeper nets: not in this version
+    if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
+    DevProb pb;
+    rc = fill_prob(prob, phi->d, &pb);
+    if (rc) return rc;
+    if (pb.kind == NOCF_PROB_QUADCOPTER) return NOCF_E_PROB;          // quadcopter adjoint: not in this version
+    DevPlan pl;
+    rc = make_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, &pl, 1);
+    if (rc) return rc;
+    if (pl.T != 4) return NOCF_E_SHAPE;
+    pl.cb = phi->cb;
+    if (workspace_bytes < plan_ws_bytes(pl)) return NOCF_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    rc = pack_weights(pl, phi, ws, st);
+    if (rc) return rc;
+    const DevPlan* plp = reinterpret_cast<const DevPlan*>(ws + pl.oPlan);
+    BwdArgs ba;
+    ba.sAll = s_all; ba.zT = z_final; ba.hs = hs; ba.n = n; ba.nt = nt; ba.nstage = (stepper == NOCF_RK4) ? 4 : 1;
+    ba.t1 = (float)t1;
+    ba.a0 = alph[0]; ba.a3 = alph[3]; ba.a4 = alph[4]; ba.a5 = alph[5]; ba.inv_n = (float)inv_n;
+    ba.Y = Y; ba.Ob = Ob; ba.V = V; ba.Ab = Ab; ba.Qb = Qb; ba.U0 = U0; ba.Wb = Wb; ba.Gb = Gb; ba.Sx = Sx;
+    ba.PHIb = PHIb; ba.lam0 = lam0;
+    const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
+    hipError_t e = set_lds(rollout_bwd_kernel<1>, ldsBytes);
+    if (e) return (int)e;
+    hipLaunchKernelGGL(rollout_bwd_kernel<1>, dim3((int)((n + 3) / 4)), dim3(pl.nwaves * 64), ldsBytes, st, plp, pb, ws, ba);
+    return (int)hipGetLastError();
 }
 
 static int phi_common(const NocfPhi* phi, const float* s, int64_t n, float* grad, float* value,

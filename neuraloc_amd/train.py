@@ -1,0 +1,106 @@
+"""Training path: `Jc = OCflow(x0, net, prob, ...); Jc.backward()` (trainOC.py:172-174) on the MI355X.
+
+A torch.autograd.Function whose forward is the fused HIP rollout (recording the stage inputs) and whose backward is
+the hand-written adjoint of the discrete RK scheme (nocf_rollout_bwd_f32, csrc/nocf_bwd.inc).  The kernel streams the
+per-evaluation vectors whose outer products are the weight gradients; the contractions over all samples and
+evaluations are plain library GEMMs (torch.matmul).  Supported: nTh = 2, Cross2D / SwarmTraj, rk4 / rk1, fp32.
+Only Jc carries a gradient (the 7 logged costs are detached, like the values trainOC prints)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_STEPPERS = {"rk4": _lib.NOCF_RK4, "rk1": _lib.NOCF_RK1}
+
+
+def _step_sizes(tspan, nt):
+    """fp32 step sizes exactly as the rollout kernels form them: (float)((tk+h)-tk), tk += h in double"""
+    h = (float(tspan[1]) - float(tspan[0])) / nt
+    tk = float(tspan[0])
+    out = []
+    for _ in range(nt):
+        out.append((tk + h) - tk)
+        tk += h
+    return torch.tensor(out, dtype=torch.float32)
+
+
+class _OCflowTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, *params):
+        x = _lib.require_device_f32(x.detach(), "x")
+        n, d = x.shape
+        dev = x.device
+        phi_st, keep1, ws = net._c_struct(n)
+        prob_st, keep2 = prob._c_struct(dev)
+        nstage = 4 if stepper == "rk4" else 1
+        persample = torch.empty(n, 7, device=dev)
+        sums = torch.empty(8, device=dev)
+        z_out = torch.empty(n, d + 4, device=dev)
+        s_all = torch.empty(nt * nstage, n, d + 1, device=dev)
+        alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+        with torch.cuda.device(dev):
+            rc = _lib.lib().nocf_rollout_record_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+                                                    float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
+                                                    _lib.ptr(z_out), _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(s_all),
+                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "nocf_rollout_record_f32")
+        ctx.net, ctx.prob, ctx.tspan, ctx.nt, ctx.stepper, ctx.alph = net, prob, tspan, nt, stepper, list(alph)
+        ctx.n_total = n_total or n
+        ctx.save_for_backward(s_all, z_out)
+        means = sums[:7] / sums[7]
+        Jc = means[0] + alph[0] * means[1] + alph[3] * means[2] + alph[4] * means[3] + alph[5] * means[4]
+        return Jc, means.detach()
+
+    @staticmethod
+    def backward(ctx, gJ, _gmeans):
+        s_all, z_out = ctx.saved_tensors
+        net, prob, nt, alph = ctx.net, ctx.prob, ctx.nt, ctx.alph
+        dev = s_all.device
+        n, d = z_out.shape[0], z_out.shape[1] - 4
+        m, D1 = net.m, d + 1
+        nstage = s_all.shape[0] // nt
+        rows = (nt * nstage + 2) * n
+        phi_st, keep1, ws = net._c_struct(n)
+        prob_st, keep2 = prob._c_struct(dev)
+        big = [torch.zeros(rows, m, device=dev) for _ in range(7)]          # Y, Ob, V, Ab, Qb, U0, Wb
+        Gb, Sx = torch.zeros(rows, D1, device=dev), torch.zeros(rows, D1, device=dev)
+        PHIb = torch.zeros(n, device=dev)
+        hs = _step_sizes(ctx.tspan, nt).to(dev)
+        alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+        with torch.cuda.device(dev):
+            rc = _lib.lib().nocf_rollout_bwd_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
+                                                 float(ctx.tspan[1]), alph_c, 1.0 / float(ctx.n_total),
+                                                 _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs),
+                                                 *[_lib.ptr(t) for t in big], _lib.ptr(Gb), _lib.ptr(Sx),
+                                                 _lib.ptr(PHIb), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "nocf_rollout_bwd_f32")
+        Y, Ob, V, Ab, Qb, U0, Wb = big
+        sT = Sx[(nt * nstage + 1) * n:]                                     # s at the final time (value rows)
+        dK0 = Y.t() @ Gb + Ob.t() @ Sx
+        db0 = Ob.sum(0)
+        dK1 = V.t() @ Ab + Qb.t() @ U0
+        db1 = Qb.sum(0)
+        dw = Wb.sum(0, keepdim=True)
+        dcw = (Gb.sum(0) + PHIb @ sT).reshape(1, -1)
+        dcb = PHIb.sum().reshape(1)
+        dM = Gb.t() @ Sx + 0.5 * (sT * PHIb[:, None]).t() @ sT
+        dA = net.A.detach() @ (dM + dM.t())
+        grads = {"A": dA, "c.weight": dcw, "c.bias": dcb, "w.weight": dw, "N.layers.0.weight": dK0,
+                 "N.layers.0.bias": db0, "N.layers.1.weight": dK1, "N.layers.1.bias": db1}
+        out = [gJ * grads[name] for name, _ in net.named_parameters()]
+        return (None,) * 8 + tuple(out)
+
+
+def ocflow_train(x, net, prob, tspan, nt, stepper, alph, n_total=None):
+    """(Jc, cs) with Jc differentiable w.r.t. the parameters of `net`.  n_total: global batch size when x is one
+    shard of it (the means of src/OCflow.py:80-86 run over all samples)."""
+    if net.nTh != 2:
+        raise NotImplementedError("the hand-written backward covers nTh = 2 networks (every shipped checkpoint); deeper: next round")
+    if type(prob).__name__ == "Quadcopter":
+        raise NotImplementedError("the hand-written backward covers Cross2D / SwarmTraj; the quadcopter adjoint is next")
+    if stepper not in _STEPPERS:
+        raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
+    params = [p for _, p in net.named_parameters()]
+    Jc, means = _OCflowTrain.apply(x, net, prob, list(tspan), int(nt), stepper, list(alph), n_total, *params)
+    return Jc, [means[i] for i in range(7)]

@@ -26,7 +26,7 @@ from src.initProb import initProb as ref_initProb      # noqa: E402
 sys.path.insert(1, REPO)          # now the repository (oracle/), behind the already-imported reference modules
 from oracle import ocflow_oracle as orc                # noqa: E402
 
-NT = {"swap2": 8, "softcorridor": 8, "swap12": 6, "swarm50": 4, "singlequad": 8}
+NT = {"swap2": 8, "softcorridor": 8, "swap12": 12, "swarm50": 20, "singlequad": 8}    # 20 = trainOC.py:29 default
 NS = 16
 
 
@@ -69,6 +69,23 @@ def main():
                 raise SystemExit(f"oracle autograd != reference autograd for {name} {k}: rel {rel:g}")
             worst = max(worst, rel)
             out[f"{name}/grad/{k}"] = gk.numpy()
+        # fp64 truth (oracle in double): lets the GPU tests bound the HIP error by the reference's own fp32-vs-fp64 gap
+        P64 = orc.PhiParams.from_state_dict({k: v.clone() for k, v in sd.items()}, dtype=torch.float64)
+        for t in [*P64.K, *P64.b, P64.w, P64.A, P64.cw, P64.cb]:
+            t.requires_grad_(True)
+        J64, _ = orc.rollout(x.double(), P64, S.to(torch.float64), [0.0, 1.0], nt, "rk4", alph)
+        J64.backward()
+        m64 = {"A": P64.A.grad, "c.weight": P64.cw.grad, "c.bias": P64.cb.grad, "w.weight": P64.w.grad}
+        for i in range(meta["nTh"]):
+            m64[f"N.layers.{i}.weight"] = P64.K[i].grad
+            m64[f"N.layers.{i}.bias"] = P64.b[i].grad
+        gap = 0.0
+        for k, gk in grads.items():
+            g64 = m64[k] if m64[k] is not None else torch.zeros_like(gk, dtype=torch.float64)
+            out[f"{name}/grad64/{k}"] = g64.numpy()
+            gap = max(gap, (gk.double() - g64).abs().max().item() / max(g64.abs().max().item(), 1e-30))
+        out[f"{name}/Jc64"] = J64.detach().numpy()
+        print(name, "reference fp32 vs fp64: Jc rel %.2e, worst grad rel %.2e" % (abs(float(Jc) - float(J64)) / abs(float(J64)), gap))
         out[f"{name}/Jc"] = Jc.detach().numpy()
         out[f"{name}/nt"] = np.array(nt)
         out[f"{name}/ns"] = np.array(NS)

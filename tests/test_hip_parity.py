@@ -230,8 +230,13 @@ def test_error_behaviour():
             na.OCflow(x, g_net, prob, [0.0, 1.0], 0)
         with pytest.raises(ValueError):
             na.OCflow(x, g_net, prob, [0.0, 1.0], 4, stepper="rk2")
+    with pytest.raises(NotImplementedError):               # training covers nTh = 2 and the point-agent problems;
+        na.OCflow(x, na.Phi(3, 8, 4).to(DEV), prob, [0.0, 1.0], 4)     # anything else refuses rather than falls back
     with pytest.raises(NotImplementedError):
-        na.OCflow(x, g_net, prob, [0.0, 1.0], 4)           # autograd through the rollout: next scope row
+        na.OCflow(torch.zeros(3, 12, device=DEV), na.Phi(2, 8, 12).to(DEV),
+                  na.Quadcopter(torch.zeros(12, device=DEV)), [0.0, 1.0], 4)
+    with pytest.raises(NotImplementedError):
+        g_net.getGrad(x)                                   # autograd through the stand-alone Phi calls: not offered
     x0 = x.clone()
     with torch.no_grad():
         na.OCflow(x, g_net, prob, [0.0, 1.0], 2)
@@ -340,3 +345,119 @@ def test_every_initprob_problem_against_oracle(name, training):
     assert bad == 0, f"{name}: {bad} state entries off (worst {worst:g})"
     bad, worst = count_off(cF.cpu(), cW, 1e-4, 1e-4 * float(cW.abs().max()) + 1e-5)
     assert bad == 0, f"{name}: {bad} control entries off (worst {worst:g})"
+
+
+# ---- training: Jc.backward() through the HIP rollout vs the reference's autograd gradients
+@pytest.mark.parametrize("name", ["swap2", "softcorridor", "swap12", "swarm50"])
+def test_backward_matches_reference_parameter_gradients(name):
+    """dJc/dtheta for every parameter vs (a) the reference's fp32 autograd (tests/golden/grads.npz, made by
+    make_golden_grads.py) and (b) the fp64 truth: the HIP error against fp64 may not exceed 4x the reference's own
+    fp32-vs-fp64 gap (plus 2e-5 of the gradient scale)."""
+    import os
+    from conftest import GOLDEN_DIR, load_golden
+    G = np.load(os.path.join(GOLDEN_DIR, "grads.npz"))
+    g = load_golden(name)
+    nt, ns = int(G[f"{name}/nt"]), int(G[f"{name}/ns"])
+    net = make_net(g, DEV)
+    net.train()
+    prob = make_prob(g, DEV, training=True)
+    x = g.t("x")[:ns].to(DEV)
+    Jc, cs = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", g.meta["alph"])
+    J64 = float(G[f"{name}/Jc64"])
+    assert abs(Jc.item() - J64) <= 1e-5 * abs(J64)
+    Jc.backward()
+    for k, p in net.named_parameters():
+        ref32 = torch.from_numpy(G[f"{name}/grad/{k}"]).double()
+        ref64 = torch.from_numpy(G[f"{name}/grad64/{k}"])
+        got = p.grad.detach().cpu().double()
+        assert got.shape == ref64.shape, k
+        scale = ref64.abs().max().item()
+        gap = (ref32 - ref64).abs().max().item()
+        err = (got - ref64).abs().max().item()
+        assert err <= 4 * gap + 2e-5 * scale + 1e-7, f"{name} {k}: err {err:g}, reference gap {gap:g}, scale {scale:g}"
+
+
+def _oracle_grads64(x, sd, prob, nt, stepper, alph, nTh):
+    P = orc.PhiParams.from_state_dict({k: v.clone() for k, v in sd.items()}, dtype=torch.float64)
+    for t in [*P.K, *P.b, P.w, P.A, P.cw, P.cb]:
+        t.requires_grad_(True)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    J, _ = orc.rollout(x.double().cpu(), P, S.to(torch.float64), [0.0, 1.0], nt, stepper, alph)
+    J.backward()
+    out = {"A": P.A.grad, "c.weight": P.cw.grad, "c.bias": P.cb.grad, "w.weight": P.w.grad}
+    for i in range(nTh):
+        out[f"N.layers.{i}.weight"], out[f"N.layers.{i}.bias"] = P.K[i].grad, P.b[i].grad
+    return float(J), out
+
+
+@pytest.mark.parametrize("name,n,stepper,training", [
+    ("midcross4", 13, "rk4", True), ("midcross4", 16, "rk1", False), ("softcorridor", 7, "rk4", True),
+    ("midcross2", 9, "rk4", False), ("swap12", 10, "rk1", True), ("swarm", 5, "rk4", True),
+    ("swap2", 1, "rk4", True), ("midcross20", 12, "rk4", True)])
+def test_backward_against_oracle_fp64_autograd(name, n, stepper, training):
+    """ragged batches, both steppers, both mask modes, obstacle / interaction problems: dJc/dtheta vs the oracle
+    differentiated by torch autograd in fp64"""
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(11)
+    prob, x0, _, _ = na.initProb(name, 24, 24, 0.5, alph, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    x0 = x0[:n].contiguous()
+    d = x0.shape[1]
+    m = 40 if d > 30 else 24
+    sd = _synth_state_dict(2, m, d, seed=len(name))
+    net = na.Phi(nTh=2, m=m, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    nt = 6
+    Jc, _ = na.OCflow(x0, net, prob, [0.0, 1.0], nt, stepper, alph)
+    Jc.backward()
+    J64, want = _oracle_grads64(x0, sd, prob, nt, stepper, alph, 2)
+    assert abs(Jc.item() - J64) <= 2e-5 * abs(J64)
+    for k, p in net.named_parameters():
+        w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()
+        scale = w.abs().max().item()
+        err = (p.grad.cpu().double() - w).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-6, f"{name} {k}: err {err:g} at scale {scale:g}"
+
+
+def test_backward_shards_add_up(golden_pretrained):
+    """n_total: gradients of two shards (each normalised by the global batch) sum to the full-batch gradient"""
+    from neuraloc_amd.train import ocflow_train
+    g = golden_pretrained
+    if g.meta["prob_class"] == "Quadcopter":
+        pytest.skip("quadcopter adjoint: next")
+    prob = make_prob(g, DEV, training=True)
+    x = g.t("x")[:24].to(DEV)
+    alph, nt = g.meta["alph"], 8
+    net_full = make_net(g, DEV).train()
+    J, _ = ocflow_train(x, net_full, prob, [0.0, 1.0], nt, "rk4", alph)
+    J.backward()
+    net_sh = make_net(g, DEV).train()
+    for xs in (x[:10], x[10:]):
+        Js, _ = ocflow_train(xs.contiguous(), net_sh, prob, [0.0, 1.0], nt, "rk4", alph, n_total=24)
+        Js.backward()
+    for (k, a), (_, b) in zip(net_full.named_parameters(), net_sh.named_parameters()):
+        scale = a.grad.abs().max().item()
+        assert (a.grad - b.grad).abs().max().item() <= 2e-5 * scale + 1e-7, k
+
+
+def test_training_step_reduces_objective(golden_pretrained):
+    """trainOC.py:160-176 in miniature: a few Adam steps through the HIP forward+backward lower Jc from a fresh net"""
+    g = golden_pretrained
+    if g.meta["prob_class"] == "Quadcopter":
+        pytest.skip("quadcopter adjoint: next")
+    torch.manual_seed(3)
+    meta = g.meta
+    net = na.Phi(nTh=2, m=meta["m"], d=meta["d"], alph=meta["alph"]).to(DEV)
+    prob = make_prob(g, DEV, training=True)
+    x = g.t("x")[:32].to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01)
+    hist = []
+    for _ in range(12):
+        opt.zero_grad()
+        Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], 8, "rk4", meta["alph"])
+        Jc.backward()
+        opt.step()
+        hist.append(Jc.item())
+    assert hist[-1] < hist[0], hist
