@@ -60,7 +60,7 @@ struct DevPlan {
     int lSB, lU0, lU1, lTH, lAV, lV0, lV1, lPART, lG, lZQ, lZ0, lZA, lDZ, lRED, lSC, lPHI, lTRIG, lPT;
     int lVEC, nVEC;                  // biases, w, c.weight and A, copied once per launch (ws floats [ob0, oPlan))
     int bwd;                         // 1: training plan (keeps tanh of the last layer, adjoint arrays, see nocf_bwd.inc)
-    int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD;   // adjoint LDS arrays (bwd plans only)
+    int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD, lSCB;   // adjoint LDS arrays (bwd plans only)
     int ldsFloats;
 };
 
@@ -1137,6 +1137,7 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, i
             pl.lAB = take(T * pl.LD); pl.lT0B = take(T * pl.LD); pl.lQB = take(T * pl.LD); pl.lOB = take(T * pl.LD);
             pl.lSBAR = take(T * pl.GLD); pl.lZQB = take(T * ZQLD);
             pl.lLAM = take(T * pl.ZLD); pl.lXS = take(T * pl.ZLD); pl.lXP = take(T * pl.ZLD); pl.lXD = take(T * pl.ZLD);
+            pl.lSCB = take(T * 4 + 8);
         }
         take(64);                                   // slack: the activation ring's last prefetch reads 32 floats past a row
         if ((size_t)l * 4 <= 160 * 1024) break;
@@ -1474,7 +1475,6 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
     DevProb pb;
     rc = fill_prob(prob, phi->d, &pb);
     if (rc) return rc;
-    if (pb.kind == NOCF_PROB_QUADCOPTER) return NOCF_E_PROB;          // quadcopter adjoint: not in this version
     DevPlan pl;
     rc = make_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, &pl, 1);
     if (rc) return rc;

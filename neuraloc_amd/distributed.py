@@ -18,11 +18,38 @@ def shard_rows(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _sum_all_reduce(t, group):
+    """in-place SUM all-reduce; RCCL ("nccl") reduces device memory directly, the gloo backend (tests: several ranks
+    sharing one GPU, or CPU tensors) goes through the host"""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def reduce_cost_sums(local_sums, group=None):
     """SUM all-reduce of the 8-vector [7 cost sums, count]; in place, returns it"""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(local_sums, op=dist.ReduceOp.SUM, group=group)
+        _sum_all_reduce(local_sums, group)
     return local_sums
+
+
+def allreduce_flat(tensors, group=None):
+    """SUM all-reduce of a list of tensors as ONE flat buffer (the parameter gradients of Phi: 415 ... 342 654
+    floats); returns new tensors of the original shapes.  One collective instead of one per parameter: over xGMI the
+    cost is latency, not bytes, at these sizes."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return list(tensors)
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    _sum_all_reduce(flat, group)
+    out, o = [], 0
+    for t in tensors:
+        out.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
+    return out
 
 
 def OCflow_sharded(x_local, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0] * 6, group=None, local_rollout=None):
@@ -32,6 +59,9 @@ def OCflow_sharded(x_local, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0] * 6,
     summation order of 8 fp32 numbers) to OCflow on the concatenated batch.
     `local_rollout` exists for the CPU/gloo tests, which inject a checker for the per-rank sums;
     the product path always uses the HIP launch."""
+    if local_rollout is None and torch.is_grad_enabled() and any(p.requires_grad for p in Phi.parameters()):
+        from .train import ocflow_train                  # training: sums and gradients are all-reduced inside
+        return ocflow_train(x_local, Phi, prob, tspan, nt, stepper, alph, group=True if group is None else group)
     if local_rollout is None:
         _, sums, _, _ = _launch(x_local, Phi, prob, tspan, nt, stepper, alph, False)
     else:

@@ -3,7 +3,7 @@
 A torch.autograd.Function whose forward is the fused HIP rollout (recording the stage inputs) and whose backward is
 the hand-written adjoint of the discrete RK scheme (nocf_rollout_bwd_f32, csrc/nocf_bwd.inc).  The kernel streams the
 per-evaluation vectors whose outer products are the weight gradients; the contractions over all samples and
-evaluations are plain library GEMMs (torch.matmul).  Supported: nTh = 2, Cross2D / SwarmTraj, rk4 / rk1, fp32.
+evaluations are plain library GEMMs (torch.matmul).  Supported: nTh = 2, Cross2D / SwarmTraj / Quadcopter, rk4 / rk1, fp32.
 Only Jc carries a gradient (the 7 logged costs are detached, like the values trainOC prints)."""
 import ctypes as C
 
@@ -27,7 +27,7 @@ def _step_sizes(tspan, nt):
 
 class _OCflowTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, *params):
+    def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
         x = _lib.require_device_f32(x.detach(), "x")
         n, d = x.shape
         dev = x.device
@@ -46,6 +46,12 @@ class _OCflowTrain(torch.autograd.Function):
                                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_record_f32")
         ctx.net, ctx.prob, ctx.tspan, ctx.nt, ctx.stepper, ctx.alph = net, prob, tspan, nt, stepper, list(alph)
+        ctx.group = group
+        if group is not None:
+            from .distributed import reduce_cost_sums
+            sums = reduce_cost_sums(sums, None if group is True else group)   # one RCCL all-reduce of 8 floats
+            if not n_total:
+                n_total = int(round(float(sums[7].item())))
         ctx.n_total = n_total or n
         ctx.save_for_backward(s_all, z_out)
         means = sums[:7] / sums[7]
@@ -89,18 +95,22 @@ class _OCflowTrain(torch.autograd.Function):
         grads = {"A": dA, "c.weight": dcw, "c.bias": dcb, "w.weight": dw, "N.layers.0.weight": dK0,
                  "N.layers.0.bias": db0, "N.layers.1.weight": dK1, "N.layers.1.bias": db1}
         out = [gJ * grads[name] for name, _ in net.named_parameters()]
-        return (None,) * 8 + tuple(out)
+        if ctx.group is not None:
+            from .distributed import allreduce_flat
+            out = allreduce_flat(out, None if ctx.group is True else ctx.group)   # one all-reduce of all gradients
+        return (None,) * 9 + tuple(out)
 
 
-def ocflow_train(x, net, prob, tspan, nt, stepper, alph, n_total=None):
+def ocflow_train(x, net, prob, tspan, nt, stepper, alph, n_total=None, group=None):
     """(Jc, cs) with Jc differentiable w.r.t. the parameters of `net`.  n_total: global batch size when x is one
-    shard of it (the means of src/OCflow.py:80-86 run over all samples)."""
+    shard of it (the means of src/OCflow.py:80-86 run over all samples).  group: a torch.distributed process group
+    (or True for the default one): the 8 cost sums are all-reduced in the forward, and the backward all-reduces the
+    parameter gradients as ONE flat buffer (<= 1.37 MB for swarm50), so Jc and .grad are the global-batch values on
+    every rank."""
     if net.nTh != 2:
         raise NotImplementedError("the hand-written backward covers nTh = 2 networks (every shipped checkpoint); deeper: next round")
-    if type(prob).__name__ == "Quadcopter":
-        raise NotImplementedError("the hand-written backward covers Cross2D / SwarmTraj; the quadcopter adjoint is next")
     if stepper not in _STEPPERS:
         raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
     params = [p for _, p in net.named_parameters()]
-    Jc, means = _OCflowTrain.apply(x, net, prob, list(tspan), int(nt), stepper, list(alph), n_total, *params)
+    Jc, means = _OCflowTrain.apply(x, net, prob, list(tspan), int(nt), stepper, list(alph), n_total, group, *params)
     return Jc, [means[i] for i in range(7)]

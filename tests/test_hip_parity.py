@@ -233,9 +233,6 @@ def test_error_behaviour():
     with pytest.raises(NotImplementedError):               # training covers nTh = 2 and the point-agent problems;
         na.OCflow(x, na.Phi(3, 8, 4).to(DEV), prob, [0.0, 1.0], 4)     # anything else refuses rather than falls back
     with pytest.raises(NotImplementedError):
-        na.OCflow(torch.zeros(3, 12, device=DEV), na.Phi(2, 8, 12).to(DEV),
-                  na.Quadcopter(torch.zeros(12, device=DEV)), [0.0, 1.0], 4)
-    with pytest.raises(NotImplementedError):
         g_net.getGrad(x)                                   # autograd through the stand-alone Phi calls: not offered
     x0 = x.clone()
     with torch.no_grad():
@@ -348,7 +345,7 @@ def test_every_initprob_problem_against_oracle(name, training):
 
 
 # ---- training: Jc.backward() through the HIP rollout vs the reference's autograd gradients
-@pytest.mark.parametrize("name", ["swap2", "softcorridor", "swap12", "swarm50"])
+@pytest.mark.parametrize("name", ["swap2", "softcorridor", "swap12", "swarm50", "singlequad"])
 def test_backward_matches_reference_parameter_gradients(name):
     """dJc/dtheta for every parameter vs (a) the reference's fp32 autograd (tests/golden/grads.npz, made by
     make_golden_grads.py) and (b) the fp64 truth: the HIP error against fp64 may not exceed 4x the reference's own
@@ -394,7 +391,8 @@ def _oracle_grads64(x, sd, prob, nt, stepper, alph, nTh):
 @pytest.mark.parametrize("name,n,stepper,training", [
     ("midcross4", 13, "rk4", True), ("midcross4", 16, "rk1", False), ("softcorridor", 7, "rk4", True),
     ("midcross2", 9, "rk4", False), ("swap12", 10, "rk1", True), ("swarm", 5, "rk4", True),
-    ("swap2", 1, "rk4", True), ("midcross20", 12, "rk4", True)])
+    ("swap2", 1, "rk4", True), ("midcross20", 12, "rk4", True), ("singlequad", 11, "rk4", True),
+    ("singlequad", 8, "rk1", False)])
 def test_backward_against_oracle_fp64_autograd(name, n, stepper, training):
     """ragged batches, both steppers, both mask modes, obstacle / interaction problems: dJc/dtheta vs the oracle
     differentiated by torch autograd in fp64"""
@@ -425,8 +423,6 @@ def test_backward_shards_add_up(golden_pretrained):
     """n_total: gradients of two shards (each normalised by the global batch) sum to the full-batch gradient"""
     from neuraloc_amd.train import ocflow_train
     g = golden_pretrained
-    if g.meta["prob_class"] == "Quadcopter":
-        pytest.skip("quadcopter adjoint: next")
     prob = make_prob(g, DEV, training=True)
     x = g.t("x")[:24].to(DEV)
     alph, nt = g.meta["alph"], 8
@@ -445,8 +441,6 @@ def test_backward_shards_add_up(golden_pretrained):
 def test_training_step_reduces_objective(golden_pretrained):
     """trainOC.py:160-176 in miniature: a few Adam steps through the HIP forward+backward lower Jc from a fresh net"""
     g = golden_pretrained
-    if g.meta["prob_class"] == "Quadcopter":
-        pytest.skip("quadcopter adjoint: next")
     torch.manual_seed(3)
     meta = g.meta
     net = na.Phi(nTh=2, m=meta["m"], d=meta["d"], alph=meta["alph"]).to(DEV)
@@ -461,3 +455,32 @@ def test_training_step_reduces_objective(golden_pretrained):
         opt.step()
         hist.append(Jc.item())
     assert hist[-1] < hist[0], hist
+
+
+def test_backward_two_quadcopters_with_interaction():
+    """Quadcopter.py:98-110 accumulates L while it subtracts it from H (the running-L loop) and adds the pair cost
+    for two craft: the adjoint carries both; checked against the fp64 oracle autograd."""
+    alph = [50.0, 0.0, 40.0, 0.5, 0.25, 0.125]
+    d, m, n, nt = 24, 24, 6, 5
+    xt = torch.zeros(d)
+    xt[0:3] = torch.tensor([2.0, 2.0, 2.0]); xt[12:15] = torch.tensor([-2.0, 2.0, 2.0])
+    prob = na.Quadcopter(xt.to(DEV), obstacle=None, alph_Q=0.0, alph_W=alph[2], r=1.5)
+    prob.train()
+    i = torch.arange(n * d, dtype=torch.float64).reshape(n, d)
+    x0 = (0.3 * torch.sin(0.7 * i + 0.2)).float()
+    x0[:, 12:15] += torch.tensor([0.8, 0.3, -0.2])             # the two craft start within 2r of each other
+    x0 = x0.to(DEV)
+    sd = _synth_state_dict(2, m, d, seed=5)
+    net = na.Phi(nTh=2, m=m, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    Jc, cs = na.OCflow(x0, net, prob, [0.0, 1.0], nt, "rk4", alph)
+    assert cs[6].item() > 0.0                                   # the interaction term is live
+    Jc.backward()
+    J64, want = _oracle_grads64(x0, sd, prob, nt, "rk4", alph, 2)
+    assert abs(Jc.item() - J64) <= 2e-5 * abs(J64)
+    for k, p in net.named_parameters():
+        w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()
+        scale = w.abs().max().item()
+        err = (p.grad.cpu().double() - w).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-6, f"{k}: err {err:g} at scale {scale:g}"

@@ -74,3 +74,26 @@ def test_shard_rows_is_a_partition():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _flat_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neuraloc_amd.distributed import allreduce_flat
+    shapes = [(10, 5), (1, 5), (1,), (1, 16), (16, 5), (16,), (16, 16), (16,)]        # Phi(2,16,4).named_parameters()
+    ts = [torch.full(s, float(rank + 1)) * (i + 1) for i, s in enumerate(shapes)]
+    out = allreduce_flat(ts)
+    ok = all(o.shape == t.shape and torch.equal(o, torch.full(t.shape, 3.0 * (i + 1))) for i, (o, t) in enumerate(zip(out, ts)))
+    ok = ok and all(torch.equal(t, torch.full(t.shape, float(rank + 1) * (i + 1))) for i, t in enumerate(ts))   # inputs untouched
+    np.save(os.path.join(out_dir, f"flat{rank}.npy"), np.array([float(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_is_one_flat_sum(tmp_path):
+    """the training backward all-reduces every parameter gradient of Phi in one flat buffer"""
+    world = 2
+    mp.spawn(_flat_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert np.load(tmp_path / "flat0.npy")[0] == 1.0 and np.load(tmp_path / "flat1.npy")[0] == 1.0

@@ -1,0 +1,66 @@
+"""GPU, two ranks sharing the one MI355X of the test box (gloo rendezvous, reductions staged through the host):
+the batch-sharded TRAINING path -- each rank rolls out and back-propagates its rows through the HIP kernels, the cost
+sums and the flat gradient buffer are all-reduced -- leaves the full-batch Jc and parameter gradients on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import neuraloc_amd as na
+    from conftest import load_golden
+    from util_hip import make_net, make_prob
+    dev = torch.device("cuda:0")
+    g = load_golden(name)
+    net = make_net(g, dev).train()
+    prob = make_prob(g, dev, training=True)
+    x = g.t("x")[:30].to(dev)
+    lo, hi = na.shard_rows(x.shape[0], rank, world)
+    Jc, cs = na.OCflow_sharded(x[lo:hi].contiguous(), net, prob, [0.0, 1.0], 8, "rk4", g.meta["alph"])
+    Jc.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), np.concatenate(([Jc.item()], flat)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["softcorridor", "swap12"])
+def test_two_rank_training_matches_full_batch(name, tmp_path):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import neuraloc_amd as na
+    from conftest import load_golden
+    from util_hip import make_net, make_prob
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert np.array_equal(r0, r1), "ranks disagree after the all-reduces"
+    dev = torch.device("cuda:0")
+    g = load_golden(name)
+    net = make_net(g, dev).train()
+    prob = make_prob(g, dev, training=True)
+    Jc, _ = na.OCflow(g.t("x")[:30].to(dev), net, prob, [0.0, 1.0], 8, "rk4", g.meta["alph"])
+    Jc.backward()
+    full = np.concatenate(([Jc.item()], torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()))
+    scale = np.abs(full[1:]).max()
+    assert abs(r0[0] - full[0]) <= 1e-5 * abs(full[0])
+    assert np.abs(r0[1:] - full[1:]).max() <= 2e-5 * scale

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""trainOC-style driver on the MI355X path.
+
+Same flags, log columns and checkpoint layout as the reference driver (trainOC.py:22-63 flags, :155-160 header,
+:176-196 iteration line, :199-207 checkpoint, :249-265 lr decay / resampling / alph switch); every OCflow call --
+forward, Jc.backward(), validation -- runs in the HIP kernels.  No plotting (viz_freq is accepted and ignored).
+
+One GPU:   python trainOC.py --data softcorridor --niters 200
+N GPUs:    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 trainOC.py ...
+           (one rank per GPU; each rank draws n_train/N samples; the 8 cost sums and one flat gradient buffer are
+           all-reduced over RCCL per iteration, so every rank takes the same Adam step)."""
+import argparse
+import datetime
+import os
+import time
+
+import torch
+
+import neuraloc_amd as na
+from neuraloc_amd.checkpoint import save_checkpoint
+from neuraloc_amd.initProb import PROBLEM_NAMES, initProb, resample
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser("Optimal Control (MI355X)")
+    p.add_argument("--data", choices=PROBLEM_NAMES, type=str, default="softcorridor")
+    p.add_argument("--nt", type=int, default=20, help="number of time steps")
+    p.add_argument("--nt_val", type=int, default=32, help="number of time steps for validation")
+    p.add_argument("--alph", type=str, default="100.0, 10000.0, 300.0, 0.2, 0.2, 0.2")   # G, Q, W, HJt, HJfin, HJgrad
+    p.add_argument("--m", type=int, default=32, help="NN width")
+    p.add_argument("--nTh", type=int, default=2, help="NN depth")
+    p.add_argument("--niters", type=int, default=1800)
+    p.add_argument("--lr", type=float, default=0.01)
+    p.add_argument("--optim", type=str, default="adam", choices=["adam"])
+    p.add_argument("--weight_decay", type=float, default=0.0)
+    p.add_argument("--resume", type=str, default=None, help="for loading a pretrained model")
+    p.add_argument("--save", type=str, default="experiments/oc/run", help="define the save directory")
+    p.add_argument("--gpu", type=int, default=0, help="send to specific gpu (single-process runs)")
+    p.add_argument("--prec", type=str, default="single", choices=["single"], help="the HIP path is fp32")
+    p.add_argument("--approach", type=str, default="ocflow", choices=["ocflow"])
+    p.add_argument("--viz_freq", type=int, default=100, help="accepted for compatibility; nothing is plotted")
+    p.add_argument("--val_freq", type=int, default=25, help="how often to run model on validation set")
+    p.add_argument("--log_freq", type=int, default=1, help="how often to print results to log")
+    p.add_argument("--lr_freq", type=int, default=600, help="how often to decrease lr")
+    p.add_argument("--lr_decay", type=float, default=0.1, help="how much to decrease lr")
+    p.add_argument("--n_train", type=int, default=1024, help="number of training samples (global)")
+    p.add_argument("--var0", type=float, default=1.0, help="variance of rho_0 to sample from")
+    p.add_argument("--sample_freq", type=int, default=100, help="how often to resample training data")
+    p.add_argument("--new_alph", type=str, default=None, help="'iter, a0, ..., a5': switch alph weights at that iteration")
+    p.add_argument("--seed", type=int, default=None, help="torch seed (rank is added); the reference is unseeded")
+    a = p.parse_args(argv)
+    a.alph = [float(v) for v in a.alph.split(",")]
+    if a.new_alph is not None:
+        a.new_alph = [float(v) for v in a.new_alph.split(",")]
+    return a
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("NOCF_TRAIN_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    else:
+        dist = None
+        dev = torch.device("cuda", args.gpu)
+    assert torch.cuda.is_available(), "trainOC.py needs an MI355X: there is no CPU path"
+    if args.seed is not None:
+        torch.manual_seed(args.seed + rank)
+    say = print if rank == 0 else (lambda *a, **k: None)
+    n_change = int(args.new_alph[0]) if args.new_alph is not None else -1
+    cvt = lambda t: t.to(torch.float32).to(dev)                        # noqa: E731
+    lo, hi = na.shard_rows(args.n_train, rank, world)
+    n_local = hi - lo
+    alph = args.alph
+    prob, x0, x0v, xInit = initProb(args.data, n_local, n_local, var0=args.var0, alph=alph, cvt=cvt)
+    d, m, nTh, tspan = x0.size(1), args.m, args.nTh, [0.0, 1.0]
+    net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)
+    if args.resume is not None:
+        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        m, nTh = ck["args"].m, ck["args"].nTh
+        net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)                      # alph from the command line wins (trainOC.py:129)
+        net.load_state_dict(ck["state_dict"])
+    net = net.to(torch.float32).to(dev)
+    if dist:                                                           # identical initial parameters on every rank
+        for prm in net.parameters():
+            dist.broadcast(prm.data, src=0)
+    optim = torch.optim.Adam(net.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    stamp = datetime.datetime.now().strftime("%Y_%m_%d_%H_%M_%S")
+    title = args.data + "_" + stamp + "_alph{:}_{:}_{:}_{:}_{:}_{:}_m{:}".format(*[int(v) for v in alph], m)
+    say("DIMENSION={:}  m={:}  nTh={:}   alpha={:}".format(d, m, nTh, alph))
+    say("nt={:}   nt_val={:}".format(args.nt, args.nt_val))
+    say("Number of trainable parameters: {}".format(sum(p.numel() for p in net.parameters() if p.requires_grad)))
+    say("data={:} device={:} ranks={:}".format(args.data, dev, world))
+    say("n_train={:}".format(args.n_train))
+    say("{:5s} {:7s} {:6s}   {:9s}  {:8s}  {:8s}  {:8s}  {:8s}  {:8s}  {:8s}  {:8s}     {:9s}  {:8s}  {:8s}  {:8s}  {:8s}  {:8s}  {:8s}  {:8s}".format(
+        "iter", "lr", "  time", "loss", "L", "G", "HJt", "HJfin", "HJgrad", "Q", "W",
+        "valLoss", "valL", "valG", "valHJt", "valHJf", "valHJg", "valQ", "valW"))
+
+    rollout = na.OCflow_sharded if dist else na.OCflow
+    best_loss, best_params, total = float("inf"), None, 0.0
+    net.train()
+    prob.train()
+    end = time.time()
+    for itr in range(1, args.niters + 1):
+        optim.zero_grad()
+        Jc, cs = rollout(x0, net, prob, tspan, args.nt, "rk4", net.alph)
+        Jc.backward()
+        optim.step()
+        torch.cuda.synchronize()
+        dt = time.time() - end
+        total += dt
+        line = "{:05d} {:7.1e} {:6.2f}   {:9.3e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}".format(
+            itr, optim.param_groups[0]["lr"], dt, Jc.item(), *[c.item() for c in cs])
+        if itr % args.val_freq == 0 or itr == args.niters:
+            with torch.no_grad():
+                net.eval()
+                prob.eval()
+                vl, vcs = rollout(x0v, net, prob, tspan, args.nt, "rk4", net.alph)   # nt, not nt_val: trainOC.py:191
+                line += "    {:9.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e} ".format(
+                    vl.item(), *[c.item() for c in vcs])
+                if vl.item() < best_loss:
+                    best_loss = vl.item()
+                    best_params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+                    if rank == 0:
+                        os.makedirs(args.save, exist_ok=True)
+                        save_checkpoint(os.path.join(args.save, title + "_checkpt.pth"), net, args)
+                net.train()
+                prob.train()
+        if itr % args.log_freq == 0:
+            say(line)
+        if itr % args.lr_freq == 0 and best_params is not None:
+            net.load_state_dict(best_params)                             # back to the best parameters so far
+            for g in optim.param_groups:
+                g["lr"] *= args.lr_decay
+        if itr % args.sample_freq == 0:
+            x0 = resample(x0, xInit, args.var0, cvt)
+        if itr == n_change:
+            # like trainOC.py:258-263: the problem is rebuilt with the new Q/W weights; net.alph (what OCflow gets) stays
+            alph = args.new_alph[1:]
+            prob, _, _, _ = initProb(args.data, n_local, n_local, var0=args.var0, alph=alph, cvt=cvt)
+            prob.train()
+            say("alph values changed")
+        end = time.time()
+    say("Training Time: {:} seconds".format(total))
+    say("Training has finished.  " + os.path.join(args.save, title))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return best_loss
+
+
+if __name__ == "__main__":
+    main()
