@@ -126,7 +126,7 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob,
 
 /*
  * Training: the pair below replaces `Jc = OCflow(...); Jc.backward()` of trainOC.py:172-173
- * for nTh = 2 networks and the point-agent problems (Cross2D, SwarmTraj).
+ * for every problem class and any depth nTh >= 2 whose activations fit the LDS (NOCF_E_LDS otherwise).
  *
  * nocf_rollout_record_f32 = nocf_rollout_f32 that also records the stage input s=[x,t] of every RK evaluation:
  *   s_all  device [nt*nstage, n, d+1]   (nstage = 4 for rk4, 1 for rk1);  z_out is required.
@@ -134,11 +134,14 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob,
  * nocf_rollout_bwd_f32 runs the exact adjoint of the discrete scheme.  It does not reduce the parameter
  * gradients itself: it streams, for every sample and evaluation, the vectors whose outer products they are,
  *   rows = (nt*nstage + 2) * n        (the two extra blocks are the terminal grad-Phi and Phi terms)
- *   Y, Ob, V, Ab, Qb, U0, Wb   device [rows, m]   (zero-initialised by the caller)
- *   Gb, Sx                     device [rows, d+1] (zero-initialised by the caller)
+ *   Y, Ob, Wb                  device [rows, m]
+ *   V, Ab, Qb, U0              device [nTh-1, rows, m]   one slab per residual layer i = 1..nTh-1
+ *   Gb, Sx                     device [rows, d+1]
+ *   (the kernel does not write the last n rows of Y, V, Ab, Gb: the caller zeroes those)
  *   PHIb                       device [n]         cotangent of Phi(x_T, t1);  lam0 device [n, d] = dJc/dx0 (nullable)
  * and the caller contracts them with library GEMMs:
- *   dK0 = Y'Gb + Ob'Sx   db0 = sum Ob   dK1 = V'Ab + Qb'U0   db1 = sum Qb   dw = sum Wb   dc.weight = sum Gb + sum PHIb s_T
+ *   dK0 = Y'Gb + Ob'Sx   db0 = sum Ob   dK_i = V_i'Ab_i + Qb_i'U0_i   db_i = sum Qb_i   dw = sum Wb
+ *   dc.weight = sum Gb + sum PHIb s_T
  *   dc.bias = sum PHIb   dM = Gb'Sx + 1/2 sum PHIb s_T s_T'   dA = A (dM + dM')
  *   hs      device [nt] fp32 step sizes as the forward used them: (float)((tk+h)-tk), tk += h in double
  *   inv_n   1 / (global batch size) -- the means of src/OCflow.py:80-86 run over all shards

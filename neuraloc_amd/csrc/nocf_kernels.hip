@@ -60,7 +60,7 @@ struct DevPlan {
     int lSB, lU0, lU1, lTH, lAV, lV0, lV1, lPART, lG, lZQ, lZ0, lZA, lDZ, lRED, lSC, lPHI, lTRIG, lPT;
     int lVEC, nVEC;                  // biases, w, c.weight and A, copied once per launch (ws floats [ob0, oPlan))
     int bwd;                         // 1: training plan (keeps tanh of the last layer, adjoint arrays, see nocf_bwd.inc)
-    int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD, lSCB;   // adjoint LDS arrays (bwd plans only)
+    int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD, lSCB, lUB;   // adjoint LDS arrays (bwd plans only)
     int ldsFloats;
 };
 
@@ -461,12 +461,16 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
     }, 1);
     __syncthreads();
     STAMP(c, 0);
-    int cur = 0;
+    // adjoint plans keep every layer's u, a and v (phi_vjp reads them); forward plans ping-pong two arrays
+    const int TLD = T * LD;
+    auto oUs = [&](int i) { return pl.bwd ? pl.lU0 + i * TLD : ((i & 1) ? pl.lU1 : pl.lU0); };     // u_i
+    auto oVs = [&](int k) { return pl.bwd ? pl.lV0 + k * TLD : ((k & 1) ? pl.lV1 : pl.lV0); };     // v_i at k = L-i (y at L)
+    auto oAs = [&](int k) { return pl.bwd ? oAV + k * TLD : oAV; };                                  // a_i at k = max(L-1-i, 0)
     // ---- residual layers, forward
     for (int i = 1; i <= lastLayer; ++i) {
         const float* bi = vec + pl.ob + (long)(i - 1) * pl.MB * 64;
         const int oTHi = oTH + i * T * LD;
-        const int oUc = cur ? pl.lU1 : pl.lU0, oUn = cur ? pl.lU0 : pl.lU1;
+        const int oUc = oUs(i - 1), oUn = oUs(i);
         gemm_phase<S>(c, pl, rg, true, phFwd(i), (i < lastLayer) ? phFwd(i + 1) : phBwd(lastLayer), oUc, LD,
                       [&](int t, int col, float v) {
             if (col < m) {
@@ -487,14 +491,13 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
             }
         }, 3);
         __syncthreads();
-        cur ^= 1;
     }
     STAMP(c, 2);
     // ---- Phi itself (final time only): w.u + 1/2 |A s|^2 + c.s + cb   (src/Phi.py:91-96)
     if (need_value) {
         const int Gsz = c.nthreads / T;
         const int t = c.tid / Gsz, j0 = c.tid - t * Gsz;
-        const int oU = cur ? pl.lU1 : pl.lU0;
+        const int oU = oUs(lastLayer);
         float acc[1] = {0.f};
         for (int col = j0; col < m; col += Gsz) acc[0] += wv[col] * lds[oU + t * LD + col];
         for (int q = j0; q < r; q += Gsz) { const float z = lds[oZQ + t * ZQLD + q]; acc[0] += 0.5f * z * z; }
@@ -504,24 +507,23 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
         __syncthreads();
     }
     // ---- backward sweep: a <- a + hN K_i^T (tanh(.) . a)
-    int vb = 0;
     for (int i = lastLayer; i >= 1; --i) {
         const int oTHp = oTH + (i - 1) * T * LD;
-        const int oVc = vb ? pl.lV1 : pl.lV0, oVn = vb ? pl.lV0 : pl.lV1;
+        const int oVc = oVs(lastLayer - i), oVn = oVs(lastLayer - i + 1);
+        const int oAc = oAs((lastLayer - 1 - i) > 0 ? (lastLayer - 1 - i) : 0), oAn = oAs(lastLayer - i);
         gemm_phase<S>(c, pl, rg, true, phBwd(i), (i > 1) ? phBwd(i - 1) : phClose, oVc, LD,
                       [&](int t, int col, float v) {
             if (col < m) {
-                const float a = lds[oAV + t * LD + col] + hN * v;
-                lds[oAV + t * LD + col] = a;
+                const float a = lds[oAc + t * LD + col] + hN * v;
+                lds[oAn + t * LD + col] = a;
                 lds[oVn + t * LD + col] = lds[oTHp + t * LD + col] * a;
             }
         }, 5);
         __syncthreads();
-        vb ^= 1;
     }
     STAMP(c, 4);
     // ---- closing: g = K0^T (tanh(o) . a) + A^T (A s) + c
-    gemm_phase<S>(c, pl, rg, true, phClose, more_evals ? phOpen : phNone, vb ? pl.lV1 : pl.lV0, LD, [&](int t, int i, float v) {
+    gemm_phase<S>(c, pl, rg, true, phClose, more_evals ? phOpen : phNone, oVs(lastLayer), LD, [&](int t, int i, float v) {
         if (i < D1) {
             float g = v + cw[i];
             for (int q = 0; q < r; ++q) g += Araw[(long)q * D1 + i] * lds[oZQ + t * ZQLD + q];
@@ -1118,9 +1120,11 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, i
         l = 0;
         auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
         pl.lSB = take(T * pl.LDs);
-        pl.lU0 = take(T * pl.LD); pl.lU1 = take(T * pl.LD);
+        const int Lr = nTh - 1, extra = (bwd && nTh > 2) ? (nTh - 2) * T * pl.LD : 0;
+        pl.lU0 = take(T * pl.LD); pl.lU1 = take(T * pl.LD + extra);          // adjoint plans: u_0 .. u_L
         pl.lTH = take((nTh - 1 + (bwd ? 1 : 0)) * T * pl.LD);
-        pl.lAV = take(T * pl.LD); pl.lV0 = take(T * pl.LD); pl.lV1 = take(T * pl.LD);
+        pl.lAV = take((bwd ? Lr : 1) * T * pl.LD);                              // adjoint plans: a_{L-1} .. a_0
+        pl.lV0 = take(T * pl.LD); pl.lV1 = take(T * pl.LD + extra);           // adjoint plans: v_L .. v_1, y
         pl.lPART = take(partFloats);
         pl.lG = take(T * pl.GLD);
         pl.lZQ = take(T * ZQLD);
@@ -1134,7 +1138,8 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, i
         pl.lVEC = take(pl.nVEC);
         if (bwd) {
             pl.lGB = take(T * pl.LDs);
-            pl.lAB = take(T * pl.LD); pl.lT0B = take(T * pl.LD); pl.lQB = take(T * pl.LD); pl.lOB = take(T * pl.LD);
+            pl.lAB = take(Lr * T * pl.LD); pl.lT0B = take(Lr * T * pl.LD); pl.lQB = take(Lr * T * pl.LD); pl.lOB = take(T * pl.LD);
+            pl.lUB = take(Lr > 1 ? T * pl.LD : 4);
             pl.lSBAR = take(T * pl.GLD); pl.lZQB = take(T * ZQLD);
             pl.lLAM = take(T * pl.ZLD); pl.lXS = take(T * pl.ZLD); pl.lXP = take(T * pl.ZLD); pl.lXD = take(T * pl.ZLD);
             pl.lSCB = take(T * 4 + 8);
@@ -1470,7 +1475,7 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
     if (rc) return rc;
     if (!alph || !s_all || !z_final || !hs || !Y || !Ob || !V || !Ab || !Qb || !U0 || !Wb || !Gb || !Sx || !PHIb || !workspace)
         return NOCF_E_NULL;
-    if (n < 1 || nt < 1 || phi->nTh != 2) return NOCF_E_SHAPE;        // deeper nets: not in this version
+    if (n < 1 || nt < 1) return NOCF_E_SHAPE;
     if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
     DevProb pb;
     rc = fill_prob(prob, phi->d, &pb);
@@ -1492,6 +1497,7 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
     ba.a0 = alph[0]; ba.a3 = alph[3]; ba.a4 = alph[4]; ba.a5 = alph[5]; ba.inv_n = (float)inv_n;
     ba.Y = Y; ba.Ob = Ob; ba.V = V; ba.Ab = Ab; ba.Qb = Qb; ba.U0 = U0; ba.Wb = Wb; ba.Gb = Gb; ba.Sx = Sx;
     ba.PHIb = PHIb; ba.lam0 = lam0;
+    ba.lstride = ((long)nt * ba.nstage + 2) * n * phi->m;
     const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
     hipError_t e = set_lds(rollout_bwd_kernel<1>, ldsBytes);
     if (e) return (int)e;

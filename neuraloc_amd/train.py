@@ -3,7 +3,7 @@
 A torch.autograd.Function whose forward is the fused HIP rollout (recording the stage inputs) and whose backward is
 the hand-written adjoint of the discrete RK scheme (nocf_rollout_bwd_f32, csrc/nocf_bwd.inc).  The kernel streams the
 per-evaluation vectors whose outer products are the weight gradients; the contractions over all samples and
-evaluations are plain library GEMMs (torch.matmul).  Supported: nTh = 2, Cross2D / SwarmTraj / Quadcopter, rk4 / rk1, fp32.
+evaluations are plain library GEMMs (torch.matmul).  Any depth nTh >= 2 (LDS permitting), Cross2D / SwarmTraj / Quadcopter, rk4 / rk1, fp32.
 Only Jc carries a gradient (the 7 logged costs are detached, like the values trainOC prints)."""
 import ctypes as C
 
@@ -69,8 +69,15 @@ class _OCflowTrain(torch.autograd.Function):
         rows = (nt * nstage + 2) * n
         phi_st, keep1, ws = net._c_struct(n)
         prob_st, keep2 = prob._c_struct(dev)
-        big = [torch.zeros(rows, m, device=dev) for _ in range(7)]          # Y, Ob, V, Ab, Qb, U0, Wb
-        Gb, Sx = torch.zeros(rows, D1, device=dev), torch.zeros(rows, D1, device=dev)
+        L = net.nTh - 1
+        # every row the kernel does not write must be zero: the value block (last n rows) of Y / V / Ab / Gb
+        Y, Ob, Wb = (torch.empty(rows, m, device=dev) for _ in range(3))
+        V, Ab, Qb, U0 = (torch.empty(L, rows, m, device=dev) for _ in range(4))     # per residual layer
+        Gb, Sx = torch.empty(rows, D1, device=dev), torch.empty(rows, D1, device=dev)
+        for t in (Y, Gb):
+            t[rows - n:].zero_()
+        for t in (V, Ab):
+            t[:, rows - n:].zero_()
         PHIb = torch.zeros(n, device=dev)
         hs = _step_sizes(ctx.tspan, nt).to(dev)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
@@ -78,22 +85,21 @@ class _OCflowTrain(torch.autograd.Function):
             rc = _lib.lib().nocf_rollout_bwd_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
                                                  float(ctx.tspan[1]), alph_c, 1.0 / float(ctx.n_total),
                                                  _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs),
-                                                 *[_lib.ptr(t) for t in big], _lib.ptr(Gb), _lib.ptr(Sx),
+                                                 _lib.ptr(Y), _lib.ptr(Ob), _lib.ptr(V), _lib.ptr(Ab), _lib.ptr(Qb),
+                                                 _lib.ptr(U0), _lib.ptr(Wb), _lib.ptr(Gb), _lib.ptr(Sx),
                                                  _lib.ptr(PHIb), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_bwd_f32")
-        Y, Ob, V, Ab, Qb, U0, Wb = big
         sT = Sx[(nt * nstage + 1) * n:]                                     # s at the final time (value rows)
-        dK0 = Y.t() @ Gb + Ob.t() @ Sx
-        db0 = Ob.sum(0)
-        dK1 = V.t() @ Ab + Qb.t() @ U0
-        db1 = Qb.sum(0)
-        dw = Wb.sum(0, keepdim=True)
-        dcw = (Gb.sum(0) + PHIb @ sT).reshape(1, -1)
-        dcb = PHIb.sum().reshape(1)
+        ones = torch.ones(1, rows, device=dev)                            # column sums as skinny GEMMs (HBM-bound reads)
+        grads = {"N.layers.0.weight": Y.t() @ Gb + Ob.t() @ Sx, "N.layers.0.bias": (ones @ Ob).reshape(-1)}
+        for i in range(1, L + 1):
+            grads[f"N.layers.{i}.weight"] = V[i - 1].t() @ Ab[i - 1] + Qb[i - 1].t() @ U0[i - 1]
+            grads[f"N.layers.{i}.bias"] = (ones @ Qb[i - 1]).reshape(-1)
+        grads["w.weight"] = ones @ Wb
+        grads["c.weight"] = ((ones @ Gb).reshape(-1) + PHIb @ sT).reshape(1, -1)
+        grads["c.bias"] = PHIb.sum().reshape(1)
         dM = Gb.t() @ Sx + 0.5 * (sT * PHIb[:, None]).t() @ sT
-        dA = net.A.detach() @ (dM + dM.t())
-        grads = {"A": dA, "c.weight": dcw, "c.bias": dcb, "w.weight": dw, "N.layers.0.weight": dK0,
-                 "N.layers.0.bias": db0, "N.layers.1.weight": dK1, "N.layers.1.bias": db1}
+        grads["A"] = net.A.detach() @ (dM + dM.t())
         out = [gJ * grads[name] for name, _ in net.named_parameters()]
         if ctx.group is not None:
             from .distributed import allreduce_flat
@@ -107,8 +113,6 @@ def ocflow_train(x, net, prob, tspan, nt, stepper, alph, n_total=None, group=Non
     (or True for the default one): the 8 cost sums are all-reduced in the forward, and the backward all-reduces the
     parameter gradients as ONE flat buffer (<= 1.37 MB for swarm50), so Jc and .grad are the global-batch values on
     every rank."""
-    if net.nTh != 2:
-        raise NotImplementedError("the hand-written backward covers nTh = 2 networks (every shipped checkpoint); deeper: next round")
     if stepper not in _STEPPERS:
         raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
     params = [p for _, p in net.named_parameters()]

@@ -230,8 +230,6 @@ def test_error_behaviour():
             na.OCflow(x, g_net, prob, [0.0, 1.0], 0)
         with pytest.raises(ValueError):
             na.OCflow(x, g_net, prob, [0.0, 1.0], 4, stepper="rk2")
-    with pytest.raises(NotImplementedError):               # training covers nTh = 2 and the point-agent problems;
-        na.OCflow(x, na.Phi(3, 8, 4).to(DEV), prob, [0.0, 1.0], 4)     # anything else refuses rather than falls back
     with pytest.raises(NotImplementedError):
         g_net.getGrad(x)                                   # autograd through the stand-alone Phi calls: not offered
     x0 = x.clone()
@@ -388,12 +386,13 @@ def _oracle_grads64(x, sd, prob, nt, stepper, alph, nTh):
     return float(J), out
 
 
-@pytest.mark.parametrize("name,n,stepper,training", [
+@pytest.mark.parametrize("name,n,stepper,training,nTh", [(a, b, c_, e, 2) for a, b, c_, e in [
     ("midcross4", 13, "rk4", True), ("midcross4", 16, "rk1", False), ("softcorridor", 7, "rk4", True),
     ("midcross2", 9, "rk4", False), ("swap12", 10, "rk1", True), ("swarm", 5, "rk4", True),
     ("swap2", 1, "rk4", True), ("midcross20", 12, "rk4", True), ("singlequad", 11, "rk4", True),
-    ("singlequad", 8, "rk1", False)])
-def test_backward_against_oracle_fp64_autograd(name, n, stepper, training):
+    ("singlequad", 8, "rk1", False)]] + [("midcross4", 9, "rk4", True, 3), ("swap12", 6, "rk4", True, 4),
+                                         ("swarm", 5, "rk4", False, 3), ("singlequad", 7, "rk4", True, 3)])
+def test_backward_against_oracle_fp64_autograd(name, n, stepper, training, nTh):
     """ragged batches, both steppers, both mask modes, obstacle / interaction problems: dJc/dtheta vs the oracle
     differentiated by torch autograd in fp64"""
     alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
@@ -403,14 +402,14 @@ def test_backward_against_oracle_fp64_autograd(name, n, stepper, training):
     x0 = x0[:n].contiguous()
     d = x0.shape[1]
     m = 40 if d > 30 else 24
-    sd = _synth_state_dict(2, m, d, seed=len(name))
-    net = na.Phi(nTh=2, m=m, d=d, alph=alph)
+    sd = _synth_state_dict(nTh, m, d, seed=len(name))
+    net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)
     net.load_state_dict(sd)
     net = net.to(DEV).train()
     nt = 6
     Jc, _ = na.OCflow(x0, net, prob, [0.0, 1.0], nt, stepper, alph)
     Jc.backward()
-    J64, want = _oracle_grads64(x0, sd, prob, nt, stepper, alph, 2)
+    J64, want = _oracle_grads64(x0, sd, prob, nt, stepper, alph, nTh)
     assert abs(Jc.item() - J64) <= 2e-5 * abs(J64)
     for k, p in net.named_parameters():
         w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()

@@ -22,8 +22,11 @@ def main():
     net = na.Phi(nTh=meta["nTh"], m=meta["m"], d=meta["d"], alph=alph)
     net.load_state_dict(sd)
     net = net.to(dev)
-    cls = {"Cross2D": na.Cross2D, "SwarmTraj": na.SwarmTraj}[meta["prob_class"]]
-    prob = cls(xtarget.to(dev), obstacle=meta["obstacle"], alph_Q=meta["alph_Q"], alph_W=meta["alph_W"], r=meta["r"])
+    if meta["prob_class"] == "Quadcopter":
+        prob = na.Quadcopter(xtarget.to(dev), obstacle=None, alph_Q=meta["alph_Q"], alph_W=meta["alph_W"])
+    else:
+        cls = {"Cross2D": na.Cross2D, "SwarmTraj": na.SwarmTraj}[meta["prob_class"]]
+        prob = cls(xtarget.to(dev), obstacle=meta["obstacle"], alph_Q=meta["alph_Q"], alph_W=meta["alph_W"], r=meta["r"])
     x = make_states(meta, xInit, meta["n_full"], seed=200).to(dev)
     net.train(); prob.train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
