@@ -60,11 +60,149 @@ struct DevPlan {
     int lSB, lU0, lU1, lTH, lAV, lV0, lV1, lPART, lG, lZQ, lZ0, lZA, lDZ, lRED, lSC, lPHI, lTRIG, lPT;
     int lVEC, nVEC;                  // biases, w, c.weight and A, copied once per launch (ws floats [ob0, oPlan))
     int bwd;                         // 1: training plan (keeps tanh of the last layer, adjoint arrays, see nocf_bwd.inc)
-    int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD, lSCB, lUB;   // adjoint LDS arrays (bwd plans only)
+    int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD, lSCB, lUB;   // adjoint
+    int pMB, pKQc;                   // column blocks per hidden phase / k-quads of the closing phase (diagnostic: halves)
     int ldsFloats;
+    int pad_;                        // keeps the struct free of implicit padding (plans are compared with memcmp)
 };
 
 static_assert(sizeof(DevPlan) % 4 == 0 && sizeof(DevPlan) / 4 <= 256, "plan copy is done by one 256-thread block");
+
+// ------------------------------------------------------------------------------------------
+// plan layout.  constexpr: the host builds the plan of any shape at run time; for the shapes named in
+// FIXED_SHAPES the same function is evaluated at COMPILE time and the kernels are instantiated with every
+// stride, offset and trip count as a literal (no scalar loads of plan fields between the phases).
+// ------------------------------------------------------------------------------------------
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+// split-K factor minimising the makespan of nblk column blocks over nwaves waves
+constexpr int choose_sk(int nblk, int halves, int nwaves, int cap) {
+    // makespan in ring halves (8 k-quads); a wave's first unit is prefetched by the previous phase, every
+    // further unit pays ~3 halves of pipeline fill; a split costs one more barrier + an LDS pass
+    int best = 1; long bestCost = -1;
+    for (int sk = 1; sk <= cap && sk <= halves; ++sk) {
+        const long rounds = cdiv(nblk * sk, nwaves);
+        const long cost = (rounds * cdiv(halves, sk) + (rounds - 1) * 3) * 16 + (sk > 1 ? 24 + 2 * sk : 0);
+        if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = sk; }
+    }
+    return best;
+}
+
+// fills the shape / image part of the plan; returns 0 or an NOCF_E_* code.  nw_req / S_req / diagHalf: 0 = default.
+constexpr int plan_layout(int d, int m, int nTh, int r, int n_agents, int bwd, int nw_req, int S_req, int diagHalf, DevPlan& out) {
+    if (d < 1 || m < 1 || nTh < 2 || nTh > MAX_NTH || r < 1 || r > d + 1 || r > ZQLD) return NOCF_E_SHAPE;
+    if (n_agents > 255) return NOCF_E_SHAPE;
+    DevPlan pl{};
+    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh; pl.bwd = bwd;
+    pl.MB = cdiv(m, 64); pl.DB = cdiv(pl.D1, 64);
+    pl.KQ1 = rup(cdiv(pl.D1, 4), HALF); pl.KQm = rup(cdiv(m, 4), HALF);
+    // geometry: waves per workgroup and sample sub-tiles
+    int nw = 1;
+    while (nw < NOCF_MAXTHREADS / 64 && nw < pl.MB) nw *= 2;
+    int S = 1;
+    if (nw_req) nw = nw_req;
+    if (S_req) S = S_req;
+    if (!(nw == 1 || nw == 2 || nw == 4 || nw == 8) || nw * 64 > NOCF_MAXTHREADS || !(S == 1 || S == 2 || S == 4)) return NOCF_E_SHAPE;
+    pl.nwaves = nw; pl.T = 4 * S;
+    // LDS row strides: 64j+4 floats keeps the four sample rows of an A-operand read on distinct 16-B slots
+    pl.LD = rup(imax(pl.KQm * 4, pl.MB * 64), 64) + 4;
+    pl.LDs = rup(pl.KQ1 * 4, 64) + 4;
+    pl.GLD = pl.DB * 64;
+    pl.ZLD = rup(d + 4, 4);
+    // packed images
+    long o4 = 0;
+    pl.oW0f = o4; o4 += (long)pl.MB * pl.KQ1 * 64;
+    pl.oW0b = o4; o4 += (long)pl.DB * pl.KQm * 64;
+    pl.strideW = (long)pl.MB * pl.KQm * 64;
+    pl.oWf = o4; o4 += (long)(nTh - 1) * pl.strideW;
+    pl.oWb = o4; o4 += (long)(nTh - 1) * pl.strideW;
+    long of = o4 * 4;
+    pl.ob0 = of; of += (long)pl.MB * 64;
+    pl.ob = of; of += (long)(nTh - 1) * pl.MB * 64;
+    pl.ow = of; of += (long)pl.MB * 64;
+    pl.ocw = of; of += (long)pl.DB * 64;
+    pl.oA = of; of += rup(r * (d + 1), 4);
+    pl.oPlan = of;
+    // LDS carve; the split-K cap shrinks until the partial-sum slots fit next to the activations
+    const int T = pl.T;
+    const int npairs = (n_agents * (n_agents - 1)) / 2;
+    int l = 0;
+    for (int cap = bwd ? 4 : MAX_SK; cap >= 1; cap >>= 1) {
+        pl.pMB = diagHalf ? imax(1, pl.MB / 2) : pl.MB;          // diagHalf: timing experiment only (results are wrong)
+        pl.pKQc = diagHalf ? imax(HALF, (pl.KQm / 2) / HALF * HALF) : pl.KQm;
+        pl.SK1 = choose_sk(pl.pMB, pl.KQ1 / HALF, nw, cap);
+        pl.SK6 = choose_sk(pl.DB, pl.pKQc / HALF, nw, cap);
+        pl.SKm = choose_sk(pl.pMB, pl.KQm / HALF, nw, cap);
+        int partFloats = 4;
+        if (pl.SK1 > 1) partFloats = imax(partFloats, pl.SK1 * T * pl.MB * 64);
+        if (pl.SKm > 1) partFloats = imax(partFloats, pl.SKm * T * pl.MB * 64);
+        if (pl.SK6 > 1) partFloats = imax(partFloats, pl.SK6 * T * pl.DB * 64);
+        l = 0;
+        const int Lr = nTh - 1, extra = (bwd && nTh > 2) ? (nTh - 2) * T * pl.LD : 0;
+        pl.lSB = l; l += rup(T * pl.LDs, 4);
+        pl.lU0 = l; l += rup(T * pl.LD, 4);
+        pl.lU1 = l; l += rup(T * pl.LD + extra, 4);                 // adjoint plans: u_0 .. u_L
+        pl.lTH = l; l += rup((nTh - 1 + (bwd ? 1 : 0)) * T * pl.LD, 4);
+        pl.lAV = l; l += rup((bwd ? Lr : 1) * T * pl.LD, 4);        // adjoint plans: a_{L-1} .. a_0
+        pl.lV0 = l; l += rup(T * pl.LD, 4);
+        pl.lV1 = l; l += rup(T * pl.LD + extra, 4);                 // adjoint plans: v_L .. v_1, y
+        pl.lPART = l; l += rup(partFloats, 4);
+        pl.lG = l; l += rup(T * pl.GLD, 4);
+        pl.lZQ = l; l += rup(T * ZQLD, 4);
+        pl.lZ0 = l; l += rup(T * pl.ZLD, 4);
+        pl.lZA = l; l += rup(T * pl.ZLD, 4);
+        pl.lDZ = l; l += rup(T * pl.ZLD, 4);
+        pl.lRED = l; l += rup(imax(T, nw) * 4, 4);
+        pl.lSC = l; l += rup(imax(T * imax(1, n_agents) + 8, T * 4 + 8), 4);
+        pl.lPHI = l; l += rup(T, 4);
+        pl.lTRIG = l; l += rup(T * imax(1, n_agents) * 6, 4);
+        pl.lPT = l; l += rup(npairs + 1, 4);
+        pl.nVEC = (int)(pl.oPlan - pl.ob0);
+        pl.lVEC = l; l += rup(pl.nVEC, 4);
+        if (bwd) {
+            pl.lGB = l; l += rup(T * pl.LDs, 4);
+            pl.lAB = l; l += rup(Lr * T * pl.LD, 4);
+            pl.lT0B = l; l += rup(Lr * T * pl.LD, 4);
+            pl.lQB = l; l += rup(Lr * T * pl.LD, 4);
+            pl.lOB = l; l += rup(T * pl.LD, 4);
+            pl.lUB = l; l += rup(Lr > 1 ? T * pl.LD : 4, 4);
+            pl.lSBAR = l; l += rup(T * pl.GLD, 4);
+            pl.lZQB = l; l += rup(T * ZQLD, 4);
+            pl.lLAM = l; l += rup(T * pl.ZLD, 4);
+            pl.lXS = l; l += rup(T * pl.ZLD, 4);
+            pl.lXP = l; l += rup(T * pl.ZLD, 4);
+            pl.lXD = l; l += rup(T * pl.ZLD, 4);
+            pl.lSCB = l; l += rup(T * 4 + 8, 4);
+        }
+        l += 64;                                    // slack: the activation ring's last prefetch reads 32 floats past a row
+        if ((long)l * 4 <= 160 * 1024) break;
+    }
+    pl.ldsFloats = l;
+    if ((long)l * 4 > 160 * 1024) return NOCF_E_LDS;
+    pl.hN = (float)(1.0 / (nTh - 1));
+    out = pl;
+    return 0;
+}
+
+// where a kernel takes its plan from: the record in the workspace (any shape) or a compile-time constant
+struct DynPlan { static constexpr bool fixed = false; };
+template <int D, int M, int NTH, int R, int NAG, int BWD>
+struct FixedPlan {
+    static constexpr bool fixed = true;
+    static constexpr DevPlan make() { DevPlan p{}; (void)plan_layout(D, M, NTH, R, NAG, BWD, 0, 0, 0, p); return p; }
+};
+// shapes with a specialised instantiation: (d, m, nTh, r, agents) of BASELINE.json's tile-kernel configurations
+#define FIXED_SHAPES(X) X(150, 512, 2, 10, 50) X(12, 128, 2, 10, 1)
+
+template <class SP>
+static bool plan_is(const DevPlan& run) {
+    static const DevPlan fixed = SP::make();
+    DevPlan a = run, b = fixed;
+    a.cb = 0.f; b.cb = 0.f;
+    return memcmp(&a, &b, sizeof(DevPlan)) == 0;
+}
 
 struct DevProb {
     int kind, obstacle, nAgents, training, agentDim;
@@ -189,9 +327,11 @@ struct Ctx {
     const float* ws;
     __amdgpu_buffer_rsrc_t wrs;      // buffer descriptor over the packed workspace (wave-uniform)
     int tid, nthreads, wave, lane;
+    float cb;                        // c.bias (the only plan field that is not a function of the shape)
 #ifdef NOCF_STAMPS
     mutable unsigned long long acc[12];
     mutable unsigned long long last;
+    unsigned long long* tl;          // timeline of ONE evaluation of workgroup 0: [wave][64 points] (null otherwise)
 #endif
 };
 
@@ -203,6 +343,7 @@ __device__ __forceinline__ void ctx_init(Ctx& c, const float* ws, unsigned ws_by
 #ifdef NOCF_STAMPS
     for (int i = 0; i < 12; ++i) c.acc[i] = 0;
     c.last = clock64();
+    c.tl = nullptr;
 #endif
 }
 
@@ -220,8 +361,10 @@ __device__ __forceinline__ float4 wload(const Ctx& c, int voff, int soff) {
 // each phase takes (barrier waits included).  The production library contains no stamp.
 #ifdef NOCF_STAMPS
 #define STAMP(c, id) do { if ((c).tid == 0) { unsigned long long t_ = clock64(); (c).acc[id] += t_ - (c).last; (c).last = t_; } } while (0)
+#define TL(c, id) do { if ((c).tl && (c).lane == 0) (c).tl[(c).wave * 64 + (id)] = clock64(); } while (0)
 #else
 #define STAMP(c, id) do { } while (0)
+#define TL(c, id) do { } while (0)
 #endif
 
 // The weight ring: two halves of 8 k-quads (8 KiB per wave each).  It lives in the kernel's scope, not
@@ -307,6 +450,9 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring
     const int arow = c.lane & 3;
     const bool want_next = nxt.SK > 0 && c.wave < nxt.nblk * nxt.SK;
     bool next_done = false;
+    const int tlb = 8 + (stamp_id >> 1) * 8;             // timeline points of this phase: tlb .. tlb+5
+    (void)tlb;
+    TL(c, tlb);
     for (int u = c.wave; u < units; u += pl.nwaves) {
         int cb, ks, h0, nh;
         unit_range(ph, u, cb, ks, h0, nh);
@@ -324,6 +470,7 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int i = 0; i < ActRing<S>::AH; ++i) av[s][i] = reinterpret_cast<const float4*>(lds)[ao + s * ld + i];
+        TL(c, tlb + 1);
         // halves alternate between rg.A and rg.B; half h is refilled with half h+2 while it is consumed
         int h = 0;
         for (; h + 3 < nh; h += 2) {
@@ -345,6 +492,7 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring
         }
         if (u + pl.nwaves >= units) {
             STAMP(c, stamp_id);                          // diagnostic: end of this wave's streaming
+            TL(c, tlb + 2);
             if (want_next) { ring_preload(c, rg, nxt, c.wave); next_done = true; }
         }
 #pragma unroll
@@ -361,12 +509,18 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring
         }
     }
     if (want_next && !next_done) ring_preload(c, rg, nxt, c.wave);     // waves without a unit in this phase
+    TL(c, tlb + 3);
     if (ph.SK > 1) {
         __syncthreads();
-        for (int t = 0; t < pl.T; ++t)
-            for (int col = c.tid; col < partLD; col += c.nthreads)
-                epi(t, col, part_sum(lds + pl.lPART, pstride, ph.SK, t * partLD + col));
+        TL(c, tlb + 4);
+        // all T*partLD outputs in one flat sweep over the whole workgroup (a closing phase has 3 column blocks: a
+        // per-sample loop would leave five of eight waves idle while the others walk the samples one after another)
+        for (int j = c.tid; j < pstride; j += c.nthreads) {
+            const int t = (j >> 6) / ph.nblk, col = j - t * partLD;
+            epi(t, col, part_sum(lds + pl.lPART, pstride, ph.SK, j));
+        }
     }
+    TL(c, tlb + 5);
 }
 
 // Segmented reduction of NV values per thread.  Threads are split into T groups of
@@ -410,7 +564,8 @@ __device__ __forceinline__ void load_vectors(const Ctx& c, const DevPlan& pl) {
 // Every thread of the workgroup must call it (it contains barriers).
 // ------------------------------------------------------------------------------------------
 template <int S>
-__device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring& rg, bool& ring_ready, bool more_evals) {
+__device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring& rg, bool& ring_ready, bool more_evals,
+                         bool z_ready = false /* z = A s already sits in ZQ (the rollout's RK tail computed it) */) {
     const int T = pl.T, LD = pl.LD, m = pl.m, D1 = pl.D1, r = pl.r;
     const int oSB = pl.lSB, oTH = pl.lTH, oAV = pl.lAV, oG = pl.lG, oZQ = pl.lZQ;
     const float hN = pl.hN;
@@ -422,17 +577,18 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
     const float* cw = vec + pl.ocw;
     const float* Araw = vec + pl.oA;
     const int lastLayer = pl.nTh - 1;
-    const PhaseDesc phOpen = {pl.oW0f, pl.MB, pl.KQ1, pl.SK1, m};
-    const PhaseDesc phClose = {pl.oW0b, pl.DB, pl.KQm, pl.SK6, D1};
+    const PhaseDesc phOpen = {pl.oW0f, pl.pMB, pl.KQ1, pl.SK1, m};
+    const PhaseDesc phClose = {pl.oW0b, pl.DB, pl.pKQc, pl.SK6, D1};
     const PhaseDesc phNone = {0, 0, 0, 0, 0};
-    auto phFwd = [&](int i) { return PhaseDesc{pl.oWf + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, m}; };
-    auto phBwd = [&](int i) { return PhaseDesc{pl.oWb + (long)(i - 1) * pl.strideW, pl.MB, pl.KQm, pl.SKm, m}; };
+    auto phFwd = [&](int i) { return PhaseDesc{pl.oWf + (long)(i - 1) * pl.strideW, pl.pMB, pl.KQm, pl.SKm, m}; };
+    auto phBwd = [&](int i) { return PhaseDesc{pl.oWb + (long)(i - 1) * pl.strideW, pl.pMB, pl.KQm, pl.SKm, m}; };
 
     STAMP(c, 10);
+    TL(c, 0);
     // the opening weights do not wait for z: start them first (unless the previous evaluation already did)
     if (!ring_ready && c.wave < phOpen.nblk * phOpen.SK) ring_preload(c, rg, phOpen, c.wave);
     // ---- z = A s (the low-rank quadratic's inner product; A is at most 10 x (d+1)).  8 lanes share a row.
-    {
+    if (!z_ready) {
         const int items = T * r * 8;
         for (int base = 0; base < items; base += c.nthreads) {
             const int id = base + c.tid;
@@ -449,6 +605,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
             if (id < items && part == 0) { const int t = tr / r; lds[oZQ + t * ZQLD + (tr - t * r)] = acc; }
         }
     }
+    TL(c, 1);
     // ---- opening layer: o = s K0^T + b0 ; u0 = sigma(o) ; gate0 = tanh(o)
     gemm_phase<S>(c, pl, rg, true, phOpen, phFwd(1), oSB, pl.LDs, [&](int t, int col, float v) {
         if (col < m) {
@@ -460,6 +617,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
         }
     }, 1);
     __syncthreads();
+    TL(c, 2);
     STAMP(c, 0);
     // adjoint plans keep every layer's u, a and v (phi_vjp reads them); forward plans ping-pong two arrays
     const int TLD = T * LD;
@@ -492,6 +650,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
         }, 3);
         __syncthreads();
     }
+    TL(c, 3);
     STAMP(c, 2);
     // ---- Phi itself (final time only): w.u + 1/2 |A s|^2 + c.s + cb   (src/Phi.py:91-96)
     if (need_value) {
@@ -503,7 +662,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
         for (int q = j0; q < r; q += Gsz) { const float z = lds[oZQ + t * ZQLD + q]; acc[0] += 0.5f * z * z; }
         for (int i = j0; i < D1; i += Gsz) acc[0] += cw[i] * lds[oSB + t * pl.LDs + i];
         group_reduce<1>(c, pl, acc);
-        if (c.tid < T) lds[pl.lPHI + c.tid] = group_total<1>(c, pl, c.tid, 0) + pl.cb;
+        if (c.tid < T) lds[pl.lPHI + c.tid] = group_total<1>(c, pl, c.tid, 0) + c.cb;
         __syncthreads();
     }
     // ---- backward sweep: a <- a + hN K_i^T (tanh(.) . a)
@@ -521,17 +680,24 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
         }, 5);
         __syncthreads();
     }
+    TL(c, 4);
     STAMP(c, 4);
     // ---- closing: g = K0^T (tanh(o) . a) + A^T (A s) + c
     gemm_phase<S>(c, pl, rg, true, phClose, more_evals ? phOpen : phNone, oVs(lastLayer), LD, [&](int t, int i, float v) {
         if (i < D1) {
+            // A^T z with a fixed trip count: the 2*ZQLD LDS reads are independent and issue back to back
+            float aq[ZQLD], zq[ZQLD];
+#pragma unroll
+            for (int q = 0; q < ZQLD; ++q) { aq[q] = (q < r) ? Araw[q * D1 + i] : 0.f; zq[q] = lds[oZQ + t * ZQLD + q]; }
             float g = v + cw[i];
-            for (int q = 0; q < r; ++q) g += Araw[(long)q * D1 + i] * lds[oZQ + t * ZQLD + q];
+#pragma unroll
+            for (int q = 0; q < ZQLD; ++q) g = fmaf(aq[q], zq[q], g);
             lds[oG + t * pl.GLD + i] = g;
         }
     }, 7);
     ring_ready = more_evals;
     __syncthreads();
+    TL(c, 5);
     STAMP(c, 6);
 }
 
@@ -688,7 +854,9 @@ __device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb)
         TRIG[(t * N + a) * 6 + q] = sn;
         TRIG[(t * N + a) * 6 + 3 + q] = cs;
     }
+    TL(c, 40);
     group_reduce<3>(c, pl, v);
+    TL(c, 41);
 }
 
 struct Costs { float L, H, Q, W; };
@@ -780,10 +948,11 @@ struct RollArgs {
 };
 
 template <int S>
-__global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan* __restrict__ plp, DevProb pb, const float* __restrict__ ws, RollArgs ra) {
-    const DevPlan& pl = *plp;                       // lives in the workspace: fields are scalar loads, not 60 pinned SGPRs
+__device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* __restrict__ plp, const DevProb& pb,
+                                             const float* __restrict__ ws, const RollArgs& ra) {
     Ctx c;
     ctx_init(c, ws, (unsigned)(pl.oPlan * 4));
+    c.cb = plp->cb;
     const int T = pl.T, d = pl.d, ZLD = pl.ZLD;
     const long row0 = (long)blockIdx.x * T;
     float* SB = lds + pl.lSB;
@@ -820,6 +989,7 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
     const float c16 = (float)(1.0 / 6.0), c26 = (float)(2.0 / 6.0);
     Ring rg;
     bool ring_ready = false;
+    bool z_next_ready = false;                      // ZQ already holds A s of the coming evaluation
     double tk = ra.t0;
     const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
     const int nsub = nstage + (ra.zFull ? 1 : 0);
@@ -833,6 +1003,7 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
         const float hs = (float)hsd;
         if (fin) {
             if (c.tid < T) SB[c.tid * pl.LDs + d] = (float)ra.t1;      // src/OCflow.py:62
+            __syncthreads();
         }
         for (int st = 0; st < (fin ? 1 : nsub); ++st) {
             if (ra.sAll && !fin && st < nstage) {           // record the stage input for the adjoint sweep
@@ -843,44 +1014,85 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
                 }
             }
             // the ring is not carried across evaluations: keeping 64 registers alive through the physics cost spills
-            phi_eval<S>(c, pl, fin, rg, ring_ready, false);
+#ifdef NOCF_STAMPS
+            c.tl = (ra.stamps && blockIdx.x == 7 && k == 40 && st == 1) ? ra.stamps + (long)gridDim.x * 12 : nullptr;
+#endif
+            phi_eval<S>(c, pl, fin, rg, ring_ready, false, z_next_ready);
+            z_next_ready = false;
             if (fin) break;
-            physics_sums(c, pl, pb);
+            // ---- RK update (src/OCflow.py:143-184): z_next accumulates, SB receives the next stage state
+            const bool stage = (st < nstage);
+            const bool last = (st == nstage - 1);
+            double tnext;
+            if (nstage == 1) tnext = t1k;
+            else tnext = (st < 2) ? (tk + hsd / 2) : (st == 2 ? (tk + hsd) : t1k);
+            // with intermediates the next evaluation is the control at (z_{k+1}, (tk+h)-h), src/OCflow.py:53
+            if (last && ra.zFull) tnext = t1k - ra.h;
+            // point agents: the state moves with -p, independent of the cost terms, so the next state is formed
+            // BEFORE the physics (into XN = DZ: the physics still reads the current x from SB) and the tail
+            // below overlaps three jobs on different waves
+            float* XN = DZ;
+            auto rk = [&](int t, int i, float dzi) {
+                const float K = hs * dzi;
+                const float z0 = Z0[t * ZLD + i];
+                float xs;
+                if (nstage == 1) { xs = z0 + K; Z0[t * ZLD + i] = xs; }
+                else if (st == 0) { ZA[t * ZLD + i] = z0 + c16 * K; xs = z0 + 0.5f * K; }
+                else if (st == 1) { ZA[t * ZLD + i] += c26 * K; xs = z0 + 0.5f * K; }
+                else if (st == 2) { ZA[t * ZLD + i] += c26 * K; xs = z0 + K; }
+                else { xs = ZA[t * ZLD + i] + c16 * K; Z0[t * ZLD + i] = xs; }
+                if (i < d) { if (quad) SB[t * pl.LDs + i] = xs; else XN[t * ZLD + i] = xs; }
+                if (last && ra.zFull && row0 + t < ra.n)
+                    ra.zFull[((long)(k + 1) * ra.n + row0 + t) * (d + 4) + i] = xs;
+            };
+            if (stage && !quad) {                           // dx = -grad_p H = -p
+                for (int t = 0; t < T; ++t)
+                    for (int i = c.tid; i < d; i += c.nthreads) rk(t, i, -G[t * pl.GLD + i]);
+            }
+            physics_sums(c, pl, pb);                        // ends with a barrier
             STAMP(c, 8);
-            if (st < nstage) {
-                // ---- RK update (src/OCflow.py:143-184): z_next accumulates, SB receives the next stage state
-                double tnext;
-                if (nstage == 1) tnext = t1k;
-                else tnext = (st < 2) ? (tk + hsd / 2) : (st == 2 ? (tk + hsd) : t1k);
-                const bool last = (st == nstage - 1);
-                // with intermediates the next evaluation is the control at (z_{k+1}, (tk+h)-h), src/OCflow.py:53
-                if (last && ra.zFull) tnext = t1k - ra.h;
-                auto rk = [&](int t, int i, float dzi) {
-                    const float K = hs * dzi;
-                    const float z0 = Z0[t * ZLD + i];
-                    float xs;
-                    if (nstage == 1) { xs = z0 + K; Z0[t * ZLD + i] = xs; }
-                    else if (st == 0) { ZA[t * ZLD + i] = z0 + c16 * K; xs = z0 + 0.5f * K; }
-                    else if (st == 1) { ZA[t * ZLD + i] += c26 * K; xs = z0 + 0.5f * K; }
-                    else if (st == 2) { ZA[t * ZLD + i] += c26 * K; xs = z0 + K; }
-                    else { xs = ZA[t * ZLD + i] + c16 * K; Z0[t * ZLD + i] = xs; }
-                    if (i < d) SB[t * pl.LDs + i] = xs;
-                    if (last && ra.zFull && row0 + t < ra.n)
-                        ra.zFull[((long)(k + 1) * ra.n + row0 + t) * (d + 4) + i] = xs;
-                };
-                if (!quad) {                                    // dx = -grad_p H = -p, all T*d components in one flat sweep
-                    for (int j = c.tid; j < T * d; j += c.nthreads) { const int t = j / d, i = j - t * d; rk(t, i, -G[t * pl.GLD + i]); }
-                }
+            if (stage) {
                 if (!quad) {
-                    if (c.tid < T) {
-                        const int s = c.tid;
+                    TL(c, 42);
+                    // tail, three jobs side by side: the last wave finishes the 4 cost components of every sample
+                    // (one lane each); the other waves compute z = A s for the NEXT evaluation from XN and move XN
+                    // into SB.  z is left to phi_eval when the next evaluation is not a plain stage.
+                    const int fw = pl.nwaves - 1;
+                    const bool split = pl.nwaves > 1;
+                    const bool zpre = !(last && (k == ra.nt - 1 || ra.zFull));
+                    if (c.wave == fw && c.lane < 4 * T) {
+                        const int s = c.lane >> 2, q = c.lane & 3;
                         const Costs cs = physics_finish(c, pl, pb, s);
-                        rk(s, d, cs.L);
-                        rk(s, d + 1, fabsf(G[s * pl.GLD + d] - cs.H));
-                        rk(s, d + 2, cs.Q);
-                        rk(s, d + 3, cs.W);
-                        SB[s * pl.LDs + d] = (float)tnext;
+                        const float val = (q == 0) ? cs.L : (q == 1) ? fabsf(G[s * pl.GLD + d] - cs.H) : (q == 2) ? cs.Q : cs.W;
+                        rk(s, d + q, val);
+                        if (q == 0) SB[s * pl.LDs + d] = (float)tnext;
                     }
+                    if (!split || c.wave != fw) {
+                        const int zt = split ? c.nthreads - 64 : c.nthreads;
+                        if (zpre) {
+                            const float* vecA = lds + pl.lVEC - pl.ob0 + pl.oA;
+                            const int r = pl.r, D1 = pl.D1;
+                            const float tn = (float)tnext;
+                            const int items = T * r * 8;
+                            for (int base = 0; base < items; base += zt) {
+                                const int id = base + c.tid;
+                                const int part = id & 7, tr = id >> 3;
+                                float acc = 0.f;
+                                if (id < items) {
+                                    const int t = tr / r, rr = tr - t * r;
+                                    const float* arow = vecA + (long)rr * D1;
+                                    for (int i = part; i < D1; i += 8) acc += arow[i] * ((i < d) ? XN[t * ZLD + i] : tn);
+                                }
+                                acc += __shfl_xor(acc, 4);
+                                acc += __shfl_xor(acc, 2);
+                                acc += __shfl_xor(acc, 1);
+                                if (id < items && part == 0) { const int t = tr / r; lds[pl.lZQ + t * ZQLD + (tr - t * r)] = acc; }
+                            }
+                        }
+                        for (int t = 0; t < T; ++t)
+                            for (int i = c.tid; i < d; i += zt) SB[t * pl.LDs + i] = XN[t * ZLD + i];
+                    }
+                    z_next_ready = zpre;
                 } else {
                     // quadcopter: one thread per sample forms the whole right-hand side (sequential agent loop of
                     // the reference), then every thread takes part in the RK update of the T*(d+4) components
@@ -902,7 +1114,9 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
                 ctrl_write(c, pl, pb, ra.ctrlFull + (long)(k + 1) * ra.n * ra.cdim, row0, ra.n, ra.cdim);
                 if (c.tid < T) SB[c.tid * pl.LDs + d] = (float)t1k;
             }
+            TL(c, 43);
             __syncthreads();
+            TL(c, 44);
             STAMP(c, 9);
         }
         tk += ra.h;
@@ -944,6 +1158,18 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan*
     }
 }
 
+// DynPlan: the plan is the record in the workspace (fields are scalar loads, not 60 pinned SGPRs).
+// FixedPlan<...>: the plan is a compile-time constant of that shape.
+template <int S, class SP>
+__global__ void __launch_bounds__(NOCF_MAXTHREADS) rollout_kernel(const DevPlan* __restrict__ plp, DevProb pb, const float* __restrict__ ws, RollArgs ra) {
+    if constexpr (SP::fixed) {
+        constexpr DevPlan plc = SP::make();
+        rollout_body<S>(plc, plp, pb, ws, ra);
+    } else {
+        rollout_body<S>(*plp, plp, pb, ws, ra);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // stand-alone Phi.getGrad / Phi.forward and problem physics (same device code as the rollout)
 // ------------------------------------------------------------------------------------------
@@ -953,6 +1179,7 @@ __global__ void __launch_bounds__(NOCF_MAXTHREADS) phi_kernel(const DevPlan* __r
     const DevPlan& pl = *plp;
     Ctx c;
     ctx_init(c, ws, (unsigned)(pl.oPlan * 4));
+    c.cb = plp->cb;
     const int T = pl.T, D1 = pl.D1;
     const long row0 = (long)blockIdx.x * T;
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
@@ -1048,110 +1275,15 @@ __global__ void store_group_plan_kernel(GroupPlan gp, float* ws) {
 // ------------------------------------------------------------------------------------------
 // host side: plan construction and the C ABI
 // ------------------------------------------------------------------------------------------
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static inline int rup(int a, int b) { return cdiv(a, b) * b; }
-
-// split-K factor minimising the makespan of nblk column blocks over nwaves waves
-static int choose_sk(int nblk, int halves, int nwaves, int cap) {
-    // makespan in ring halves (8 k-quads); a wave's first unit is prefetched by the previous phase, every
-    // further unit pays ~3 halves of pipeline fill; a split costs one more barrier + an LDS pass
-    int best = 1; long bestCost = -1;
-    for (int sk = 1; sk <= cap && sk <= halves; ++sk) {
-        const long rounds = cdiv(nblk * sk, nwaves);
-        const long cost = (rounds * cdiv(halves, sk) + (rounds - 1) * 3) * 16 + (sk > 1 ? 24 + 2 * sk : 0);
-        if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = sk; }
-    }
-    return best;
-}
-
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
 
-// fills the shape / image part of the plan; returns 0 or an NOCF_E_* code
+// host wrapper: geometry knobs from the environment, then the (constexpr) layout
 static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, int bwd = 0) {
-    if (d < 1 || m < 1 || nTh < 2 || nTh > MAX_NTH || r < 1 || r > d + 1 || r > ZQLD) return NOCF_E_SHAPE;
-    if (n_agents > 255) return NOCF_E_SHAPE;
-    DevPlan pl;
-    memset(&pl, 0, sizeof(pl));
-    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh; pl.bwd = bwd;
-    pl.MB = cdiv(m, 64); pl.DB = cdiv(pl.D1, 64);
-    pl.KQ1 = rup(cdiv(pl.D1, 4), HALF); pl.KQm = rup(cdiv(m, 4), HALF);
-    // geometry: waves per workgroup and sample sub-tiles
-    int nw = 1;
-    while (nw < NOCF_MAXTHREADS / 64 && nw < pl.MB) nw *= 2;
-    int S = 1;
-    nw = env_int("NOCF_NWAVES", nw);
-    S = env_int("NOCF_SUBTILES", S);
-    if (!(nw == 1 || nw == 2 || nw == 4 || nw == 8) || nw * 64 > NOCF_MAXTHREADS || !(S == 1 || S == 2 || S == 4)) return NOCF_E_SHAPE;
-    pl.nwaves = nw; pl.T = 4 * S;
-    // LDS row strides: 64j+4 floats keeps the four sample rows of an A-operand read on distinct 16-B slots
-    pl.LD = rup(std::max(pl.KQm * 4, pl.MB * 64), 64) + 4;
-    pl.LDs = rup(pl.KQ1 * 4, 64) + 4;
-    pl.GLD = pl.DB * 64;
-    pl.ZLD = rup(d + 4, 4);
-    // packed images
-    long o4 = 0;
-    pl.oW0f = o4; o4 += (long)pl.MB * pl.KQ1 * 64;
-    pl.oW0b = o4; o4 += (long)pl.DB * pl.KQm * 64;
-    pl.strideW = (long)pl.MB * pl.KQm * 64;
-    pl.oWf = o4; o4 += (long)(nTh - 1) * pl.strideW;
-    pl.oWb = o4; o4 += (long)(nTh - 1) * pl.strideW;
-    long of = o4 * 4;
-    pl.ob0 = of; of += (long)pl.MB * 64;
-    pl.ob = of; of += (long)(nTh - 1) * pl.MB * 64;
-    pl.ow = of; of += (long)pl.MB * 64;
-    pl.ocw = of; of += (long)pl.DB * 64;
-    pl.oA = of; of += rup(r * (d + 1), 4);
-    pl.oPlan = of;
-    // LDS carve; the split-K cap shrinks until the partial-sum slots fit next to the activations
-    const int T = pl.T;
-    const int npairs = (n_agents * (n_agents - 1)) / 2;
-    int l = 0;
-    for (int cap = bwd ? 4 : MAX_SK; cap >= 1; cap >>= 1) {
-        pl.SK1 = choose_sk(pl.MB, pl.KQ1 / HALF, nw, cap);
-        pl.SK6 = choose_sk(pl.DB, pl.KQm / HALF, nw, cap);
-        pl.SKm = choose_sk(pl.MB, pl.KQm / HALF, nw, cap);
-        int partFloats = 4;
-        if (pl.SK1 > 1) partFloats = std::max(partFloats, pl.SK1 * T * pl.MB * 64);
-        if (pl.SKm > 1) partFloats = std::max(partFloats, pl.SKm * T * pl.MB * 64);
-        if (pl.SK6 > 1) partFloats = std::max(partFloats, pl.SK6 * T * pl.DB * 64);
-        l = 0;
-        auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
-        pl.lSB = take(T * pl.LDs);
-        const int Lr = nTh - 1, extra = (bwd && nTh > 2) ? (nTh - 2) * T * pl.LD : 0;
-        pl.lU0 = take(T * pl.LD); pl.lU1 = take(T * pl.LD + extra);          // adjoint plans: u_0 .. u_L
-        pl.lTH = take((nTh - 1 + (bwd ? 1 : 0)) * T * pl.LD);
-        pl.lAV = take((bwd ? Lr : 1) * T * pl.LD);                              // adjoint plans: a_{L-1} .. a_0
-        pl.lV0 = take(T * pl.LD); pl.lV1 = take(T * pl.LD + extra);           // adjoint plans: v_L .. v_1, y
-        pl.lPART = take(partFloats);
-        pl.lG = take(T * pl.GLD);
-        pl.lZQ = take(T * ZQLD);
-        pl.lZ0 = take(T * pl.ZLD); pl.lZA = take(T * pl.ZLD); pl.lDZ = take(T * pl.ZLD);
-        pl.lRED = take(std::max(T, nw) * 4);
-        pl.lSC = take(std::max(T * std::max(1, n_agents) + 8, T * 4 + 8));
-        pl.lPHI = take(T);
-        pl.lTRIG = take(T * std::max(1, n_agents) * 6);
-        pl.lPT = take(npairs + 1);
-        pl.nVEC = (int)(pl.oPlan - pl.ob0);
-        pl.lVEC = take(pl.nVEC);
-        if (bwd) {
-            pl.lGB = take(T * pl.LDs);
-            pl.lAB = take(Lr * T * pl.LD); pl.lT0B = take(Lr * T * pl.LD); pl.lQB = take(Lr * T * pl.LD); pl.lOB = take(T * pl.LD);
-            pl.lUB = take(Lr > 1 ? T * pl.LD : 4);
-            pl.lSBAR = take(T * pl.GLD); pl.lZQB = take(T * ZQLD);
-            pl.lLAM = take(T * pl.ZLD); pl.lXS = take(T * pl.ZLD); pl.lXP = take(T * pl.ZLD); pl.lXD = take(T * pl.ZLD);
-            pl.lSCB = take(T * 4 + 8);
-        }
-        take(64);                                   // slack: the activation ring's last prefetch reads 32 floats past a row
-        if ((size_t)l * 4 <= 160 * 1024) break;
-    }
-    pl.ldsFloats = l;
-    if ((size_t)l * 4 > 160 * 1024) return NOCF_E_LDS;
-    pl.hN = (float)(1.0 / (nTh - 1));
-    *out = pl;
-    return 0;
+    return plan_layout(d, m, nTh, r, n_agents, bwd, env_int("NOCF_NWAVES", 0), env_int("NOCF_SUBTILES", 0),
+                       env_int("NOCF_DIAG_HALF", 0), *out);
 }
 
 // Group (weight-sliced) plan: returns 0 and fills *out when the shape qualifies, else an NOCF_E_* code.
@@ -1430,13 +1562,30 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
             (void)hipEventRecord(ev0, st);
         }
-        switch (pl.T / 4) {
-            case 1: e = set_lds(rollout_kernel<1>, ldsBytes); if (e) return (int)e;
-                    hipLaunchKernelGGL(rollout_kernel<1>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
-            case 2: e = set_lds(rollout_kernel<2>, ldsBytes); if (e) return (int)e;
-                    hipLaunchKernelGGL(rollout_kernel<2>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
-            default: e = set_lds(rollout_kernel<4>, ldsBytes); if (e) return (int)e;
-                    hipLaunchKernelGGL(rollout_kernel<4>, dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
+        bool launched = false;
+        if (pl.T == 4 && env_int("NOCF_FIXED", 1)) {
+            // shape-specialised instantiations (FIXED_SHAPES): taken only when the run-time plan equals the
+            // compile-time one bit for bit, so the environment knobs and odd shapes always get the generic kernel
+            const void* fk = nullptr;
+#define NOCF_TRY_FIXED(D, M, NTH, R, NAG) \
+            if (!fk && plan_is<FixedPlan<D, M, NTH, R, NAG, 0>>(pl)) fk = reinterpret_cast<const void*>(rollout_kernel<1, FixedPlan<D, M, NTH, R, NAG, 0>>);
+            FIXED_SHAPES(NOCF_TRY_FIXED)
+#undef NOCF_TRY_FIXED
+            if (fk) {
+                e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
+                void* args[] = {(void*)&plp, (void*)&pb, (void*)&ws, (void*)&ra};
+                e = hipLaunchKernel(fk, dim3(grid), dim3(block), args, ldsBytes, st); if (e) return (int)e;
+                launched = true;
+                if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] shape-specialised rollout kernel\n");
+            }
+        }
+        if (!launched) switch (pl.T / 4) {
+            case 1: e = set_lds(rollout_kernel<1, DynPlan>, ldsBytes); if (e) return (int)e;
+                    hipLaunchKernelGGL((rollout_kernel<1, DynPlan>), dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
+            case 2: e = set_lds(rollout_kernel<2, DynPlan>, ldsBytes); if (e) return (int)e;
+                    hipLaunchKernelGGL((rollout_kernel<2, DynPlan>), dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
+            default: e = set_lds(rollout_kernel<4, DynPlan>, ldsBytes); if (e) return (int)e;
+                    hipLaunchKernelGGL((rollout_kernel<4, DynPlan>), dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;
         }
     }
     e = hipGetLastError();
@@ -1499,9 +1648,9 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
     ba.PHIb = PHIb; ba.lam0 = lam0;
     ba.lstride = ((long)nt * ba.nstage + 2) * n * phi->m;
     const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
-    hipError_t e = set_lds(rollout_bwd_kernel<1>, ldsBytes);
+    hipError_t e = set_lds(rollout_bwd_kernel<1, DynPlan>, ldsBytes);
     if (e) return (int)e;
-    hipLaunchKernelGGL(rollout_bwd_kernel<1>, dim3((int)((n + 3) / 4)), dim3(pl.nwaves * 64), ldsBytes, st, plp, pb, ws, ba);
+    hipLaunchKernelGGL((rollout_bwd_kernel<1, DynPlan>), dim3((int)((n + 3) / 4)), dim3(pl.nwaves * 64), ldsBytes, st, plp, pb, ws, ba);
     return (int)hipGetLastError();
 }
 
