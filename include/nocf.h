@@ -185,6 +185,8 @@ int nocf_profile_end(double* total_ms, int32_t* launches);
 /* Diagnostic builds (-DNOCF_STAMPS, libnocf_stamps.so) only: device buffer of 12 uint64 per
  * workgroup receiving per-phase shader-cycle totals.  The production library returns an error. */
 int nocf_debug_set_stamp_buffer(void* device_buf);
+/* diagnostic builds only: [8 waves][64 points] shader-clock timeline of one evaluation of the adjoint kernel */
+int nocf_debug_set_timeline_buffer(void* device_buf);
 
 /* layout probe used by the tests: D = sum_k A_k B_k through the same 4x4x1 MFMA tile code
  * the rollout uses.  a: device [4, K], b: device [K, 64] -> out: device [4, 64] */

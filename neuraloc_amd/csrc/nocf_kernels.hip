@@ -195,6 +195,8 @@ struct FixedPlan {
 };
 // shapes with a specialised instantiation: (d, m, nTh, r, agents) of BASELINE.json's tile-kernel configurations
 #define FIXED_SHAPES(X) X(150, 512, 2, 10, 50) X(12, 128, 2, 10, 1)
+// the small BASELINE shapes: evaluation takes the lane kernel, TRAINING (record + adjoint) takes the tile kernels
+#define FIXED_SHAPES_TRAIN(X) X(4, 16, 2, 5, 2) X(4, 32, 2, 5, 2) X(24, 32, 2, 10, 12)
 
 template <class SP>
 static bool plan_is(const DevPlan& run) {
@@ -362,6 +364,7 @@ __device__ __forceinline__ float4 wload(const Ctx& c, int voff, int soff) {
 #ifdef NOCF_STAMPS
 #define STAMP(c, id) do { if ((c).tid == 0) { unsigned long long t_ = clock64(); (c).acc[id] += t_ - (c).last; (c).last = t_; } } while (0)
 #define TL(c, id) do { if ((c).tl && (c).lane == 0) (c).tl[(c).wave * 64 + (id)] = clock64(); } while (0)
+__device__ unsigned long long* g_tl_dev = nullptr;       // timeline buffer of the adjoint kernel (set with the stamp buffer)
 #else
 #define STAMP(c, id) do { } while (0)
 #define TL(c, id) do { } while (0)
@@ -473,6 +476,9 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring
         TL(c, tlb + 1);
         // halves alternate between rg.A and rg.B; half h is refilled with half h+2 while it is consumed
         int h = 0;
+        // never unrolled: with a compile-time trip count the scheduler otherwise sinks every refill load down to
+        // its first use (vmcnt(1) everywhere) and the ring's prefetch distance is gone
+#pragma clang loop unroll(disable)
         for (; h + 3 < nh; h += 2) {
             ring_half<S, true, true>(c, rg.A, av, acc, ao, ld, voff, wo + 2 * HALF * 1024);
             ring_half<S, true, true>(c, rg.B, av, acc, ao + HALF, ld, voff, wo + 3 * HALF * 1024);
@@ -1414,6 +1420,16 @@ int nocf_debug_set_stamp_buffer(void* device_buf) {
 #endif
 }
 
+int nocf_debug_set_timeline_buffer(void* device_buf) {
+#ifdef NOCF_STAMPS
+    unsigned long long* p = (unsigned long long*)device_buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_dev), &p, sizeof(p));
+#else
+    (void)device_buf;
+    return NOCF_E_SHAPE;                                 // production build carries no stamps
+#endif
+}
+
 int nocf_profile_begin(void) {
     for (auto& pr : g_prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     g_prof_events.clear();
@@ -1570,6 +1586,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
 #define NOCF_TRY_FIXED(D, M, NTH, R, NAG) \
             if (!fk && plan_is<FixedPlan<D, M, NTH, R, NAG, 0>>(pl)) fk = reinterpret_cast<const void*>(rollout_kernel<1, FixedPlan<D, M, NTH, R, NAG, 0>>);
             FIXED_SHAPES(NOCF_TRY_FIXED)
+            if (s_all) { FIXED_SHAPES_TRAIN(NOCF_TRY_FIXED) }
 #undef NOCF_TRY_FIXED
             if (fk) {
                 e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
@@ -1648,9 +1665,22 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
     ba.PHIb = PHIb; ba.lam0 = lam0;
     ba.lstride = ((long)nt * ba.nstage + 2) * n * phi->m;
     const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
-    hipError_t e = set_lds(rollout_bwd_kernel<1, DynPlan>, ldsBytes);
+    const void* fk = nullptr;
+    if (env_int("NOCF_FIXED", 1)) {
+#define NOCF_TRY_FIXED(D, M, NTH, R, NAG) \
+        if (!fk && plan_is<FixedPlan<D, M, NTH, R, NAG, 1>>(pl)) fk = reinterpret_cast<const void*>(rollout_bwd_kernel<1, FixedPlan<D, M, NTH, R, NAG, 1>>);
+        FIXED_SHAPES(NOCF_TRY_FIXED)
+        FIXED_SHAPES_TRAIN(NOCF_TRY_FIXED)
+#undef NOCF_TRY_FIXED
+    }
+    if (!fk) fk = reinterpret_cast<const void*>(rollout_bwd_kernel<1, DynPlan>);
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e) return (int)e;
-    hipLaunchKernelGGL((rollout_bwd_kernel<1, DynPlan>), dim3((int)((n + 3) / 4)), dim3(pl.nwaves * 64), ldsBytes, st, plp, pb, ws, ba);
+    {
+        void* args[] = {(void*)&plp, (void*)&pb, (void*)&ws, (void*)&ba};
+        e = hipLaunchKernel(fk, dim3((int)((n + 3) / 4)), dim3(pl.nwaves * 64), args, ldsBytes, st);
+        if (e) return (int)e;
+    }
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Diagnostic (-DNOCF_STAMPS build): per-wave timeline of ONE evaluation of the adjoint kernel (workgroup 7)."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ.setdefault("NOCF_LIB_PATH", os.path.join(REPO, "neuraloc_amd", "csrc", "libnocf_stamps.so"))
+
+import torch                                   # noqa: E402
+import bench                                   # noqa: E402
+import neuraloc_amd as na                      # noqa: E402
+from neuraloc_amd import _lib                  # noqa: E402
+
+POINTS = {38: "eval: s loaded", 0: "phi_eval entry", 2: "open barrier", 3: "fwd barrier", 4: "bwd barrier", 5: "close barrier",
+          39: "phi_eval done", 41: "physics reduce barrier", 45: "physics done", 46: "cotangents formed", 47: "xgrad done",
+          54: "vjp: zb done", 55: "vjp: ybar phase done", 56: "vjp: vbar phase done", 57: "vjp: ubar phase done",
+          58: "vjp: closing done", 59: "vjp: rows streamed"}
+ORDER = [38, 0, 2, 3, 4, 5, 39, 41, 45, 46, 47, 54, 55, 56, 57, 58, 59]
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "swarm50"
+    meta, sd, xtarget, xInit = bench.load_workload(wl)
+    dev = torch.device("cuda:0")
+    net = na.Phi(nTh=meta["nTh"], m=meta["m"], d=meta["d"], alph=meta["alph"])
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    cls = {"Cross2D": na.Cross2D, "SwarmTraj": na.SwarmTraj, "Quadcopter": na.Quadcopter}[meta["prob_class"]]
+    kw = {} if meta["prob_class"] == "Quadcopter" else {"r": meta["r"]}
+    prob = cls(xtarget.to(dev), obstacle=meta["obstacle"], alph_Q=meta["alph_Q"], alph_W=meta["alph_W"], **kw)
+    prob.train()
+    n, nt = meta["n_full"], meta["nt"]
+    x = bench.make_states(meta, xInit, n, 200).to(dev)
+    buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    L.nocf_debug_set_timeline_buffer.argtypes = [__import__("ctypes").c_void_p]
+    assert L.nocf_debug_set_timeline_buffer(buf.data_ptr()) == 0, "this is not the NOCF_STAMPS build"
+    Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", meta["alph"])
+    Jc.backward()
+    torch.cuda.synchronize()
+    tl = buf.view(8, 64).cpu()
+    t0 = int(tl[:, 38][tl[:, 38] > 0].min())
+    print(f"{'point':28s}" + "".join(f"   wave{w}" for w in range(8)))
+    for p in ORDER:
+        row = [int(tl[w, p]) - t0 if int(tl[w, p]) > 0 else -1 for w in range(8)]
+        print(f"{POINTS[p]:28s}" + "".join(f"{v:8d}" for v in row))
+
+
+if __name__ == "__main__":
+    main()
