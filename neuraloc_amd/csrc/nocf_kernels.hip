@@ -127,7 +127,7 @@ constexpr int plan_layout(int d, int m, int nTh, int r, int n_agents, int bwd, i
     pl.oPlan = of;
     // LDS carve; the split-K cap shrinks until the partial-sum slots fit next to the activations
     const int T = pl.T;
-    const int npairs = (n_agents * (n_agents - 1)) / 2;
+    (void)n_agents;
     int l = 0;
     for (int cap = bwd ? 4 : MAX_SK; cap >= 1; cap >>= 1) {
         pl.pMB = diagHalf ? imax(1, pl.MB / 2) : pl.MB;          // diagHalf: timing experiment only (results are wrong)
@@ -158,7 +158,7 @@ constexpr int plan_layout(int d, int m, int nTh, int r, int n_agents, int bwd, i
         pl.lSC = l; l += rup(imax(T * imax(1, n_agents) + 8, T * 4 + 8), 4);
         pl.lPHI = l; l += rup(T, 4);
         pl.lTRIG = l; l += rup(T * imax(1, n_agents) * 6, 4);
-        pl.lPT = l; l += rup(npairs + 1, 4);
+        pl.lPT = l; l += 4;                                         // (spare)
         pl.nVEC = (int)(pl.oPlan - pl.ob0);
         pl.lVEC = l; l += rup(pl.nVEC, 4);
         if (bwd) {
@@ -765,45 +765,56 @@ __device__ __forceinline__ bool want_W(const DevProb& pb) {
     return (pb.kind == NOCF_PROB_QUADCOPTER) ? (pb.alphW > 0.0) : (pb.alphW != 0.0);
 }
 
-// pair table for the N>2 interaction sum: entry p = (ad*i << 16) | ad*j for i < j, i.e. the two agents' float
-// offsets inside a state row, so the hot loop needs no multiply   (built once per launch)
-__device__ void build_pair_table(const Ctx& c, const DevPlan& pl, const DevProb& pb) {
-    if (pb.kind == NOCF_PROB_QUADCOPTER || pb.nAgents <= 2 || !want_W(pb)) return;
-    unsigned* PT = reinterpret_cast<unsigned*>(lds + pl.lPT);
-    const int N = pb.nAgents, ad = pb.agentDim;
-    for (int idx = c.tid; idx < N * N; idx += c.nthreads) {
-        const int i = idx / N, j = idx - i * N;
-        if (i < j) PT[i * N - (i * (i + 1)) / 2 + (j - i - 1)] = ((unsigned)(i * ad) << 16) | (unsigned)(j * ad);
-    }
-}
-
-// squared distances of 4 agent pairs per trip (all LDS reads issued before the first use), PD = 2 or 3
+// Interaction sum of one sample by cyclic pairing: agent a meets its partners (a+j) mod N, j = 1..(N-1)/2 (for
+// even N the opposite agent j = N/2 as well, counted from the lower half only), so every unordered pair appears
+// once, every agent has the same number of partners, x_a stays in registers and consecutive lanes read
+// consecutive agents (stride PD floats: conflict-free).  The Gsz threads of the sample's group are used as
+// P = Gsz / N parts of the partner range.  Returns this thread's partial sum.
 template <int PD>
-__device__ __forceinline__ float pair_sum(const float* __restrict__ x, const unsigned* __restrict__ PT, int npairs,
-                                          int j0, int Gsz, float thr, float thr2, float den) {
+__device__ __forceinline__ float pair_sum_cyclic(const float* __restrict__ x, int N, int j0, int Gsz, float thr, float thr2, float den) {
+    const int J = (N - 1) >> 1;                       // partners every agent meets
+    const bool even = (N & 1) == 0;
+    int lgP = 0;                                      // P = 2^lgP parts of the partner range (no integer division below)
+    while ((2 * N << lgP) <= Gsz && (2 << lgP) <= J) ++lgP;
+    const int P = 1 << lgP;
     float w = 0.f;
-    for (int q0 = j0; q0 < npairs; q0 += 4 * Gsz) {
-        unsigned ij[4];
+    for (int q = j0; q < N * P; q += Gsz) {
+        int part = 0, a = q;
+        while (a >= N) { a -= N; ++part; }
+        float xa[PD];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int q = q0 + u * Gsz; ij[u] = PT[q < npairs ? q : 0]; }
-        float s2[4];
+        for (int k = 0; k < PD; ++k) xa[k] = x[PD * a + k];
+        const int jlo = 1 + ((J * part) >> lgP), jhi = 1 + ((J * (part + 1)) >> lgP);   // [jlo, jhi)
+        int b = a + jlo; if (b >= N) b -= N;
+        for (int j = jlo; j < jhi; j += 4) {
+            float s2[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* xi = x + (ij[u] >> 16);
-            const float* xj = x + (ij[u] & 0xffffu);
+            for (int u = 0; u < 4; ++u) {
+                int bu = b + u; if (bu >= N) bu -= N;
+                float a2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < PD; ++k) { const float e = xa[k] - x[PD * bu + k]; a2 += e * e; }
+                s2[u] = (j + u < jhi) ? a2 : 3.0e38f;
+            }
+            b += 4; if (b >= N) b -= N;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (s2[u] < thr2) {                                  // cheap reject; the exact test follows
+                    const float dist = sqrtf(s2[u]);
+                    if (dist < thr) {
+                        const float e = expf(-(dist * dist) / den);
+                        if (e != 1.f) w += e;                        // the reference drops entries equal to 1.
+                    }
+                }
+            }
+        }
+        if (even && part == P - 1 && a < (N >> 1)) {                 // the opposite agent, once per pair
             float a2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < PD; ++k) { const float e = xi[k] - xj[k]; a2 += e * e; }
-            s2[u] = (q0 + u * Gsz < npairs) ? a2 : 3.0e38f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (s2[u] < thr2) {                                  // cheap reject; the exact test follows
-                const float dist = sqrtf(s2[u]);
-                if (dist < thr) {
-                    const float e = expf(-(dist * dist) / den);
-                    if (e != 1.f) w += e;                        // the reference drops entries equal to 1.
-                }
+            for (int k = 0; k < PD; ++k) { const float e = xa[k] - x[PD * (a + (N >> 1)) + k]; a2 += e * e; }
+            if (a2 < thr2) {
+                const float dist = sqrtf(a2);
+                if (dist < thr) { const float e = expf(-(dist * dist) / den); if (e != 1.f) w += e; }
             }
         }
     }
@@ -824,7 +835,9 @@ __device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb)
     const float* p = P + t * pl.GLD;
 
     float v[3] = {0.f, 0.f, 0.f};
+    TL(c, 6);
     for (int i = j0; i < d; i += Gsz) v[0] += p[i] * p[i];
+    TL(c, 7);
     if (pb.kind == NOCF_PROB_CROSS2D) {
         if (pb.obstacle != NOCF_OBS_NONE)
             for (int a = j0; a < N; a += Gsz) v[1] += obstacle_cross2d(pb, x[2 * a], x[2 * a + 1]);
@@ -832,6 +845,7 @@ __device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb)
         if (pb.obstacle != NOCF_OBS_NONE && pb.alphQ > 0.0)
             for (int a = j0; a < N; a += Gsz) v[1] += obstacle_swarm(pb, x[3 * a], x[3 * a + 1], x[3 * a + 2]);
     }
+    TL(c, 14);
     if (want_W(pb) && N >= 2) {
         const float den = (float)(2.0 * pb.r * pb.r);
         const int pd = (pb.kind == NOCF_PROB_CROSS2D) ? 2 : 3;      // position components per agent
@@ -847,10 +861,8 @@ __device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb)
             const double fac = pb.training ? (pb.kind == NOCF_PROB_SWARMTRAJ ? 3.2 : 2.2) : 2.0;
             const float thr = (float)(fac * pb.r);
             const float thr2 = thr * thr * 1.000002f;
-            const unsigned* PT = reinterpret_cast<const unsigned*>(Lm + pl.lPT);
-            const int npairs = (N * (N - 1)) / 2;
-            v[2] = (pd == 3) ? pair_sum<3>(x, PT, npairs, j0, Gsz, thr, thr2, den)
-                             : pair_sum<2>(x, PT, npairs, j0, Gsz, thr, thr2, den);
+            v[2] = (pd == 3) ? pair_sum_cyclic<3>(x, N, j0, Gsz, thr, thr2, den)
+                             : pair_sum_cyclic<2>(x, N, j0, Gsz, thr, thr2, den);
         }
     }
     if (pb.kind == NOCF_PROB_QUADCOPTER && j0 < 3 * N) {       // sin/cos of (psi, theta, phi) per agent
@@ -970,7 +982,6 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
     __syncthreads();
     load_vectors(c, pl);
-    build_pair_table(c, pl, pb);
     for (int t = 0; t < T; ++t) {
         long row = row0 + t; if (row >= ra.n) row = ra.n - 1;          // tail rows replicate a valid sample
         for (int i = c.tid; i < d; i += c.nthreads) {
@@ -1051,9 +1062,12 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
                 if (last && ra.zFull && row0 + t < ra.n)
                     ra.zFull[((long)(k + 1) * ra.n + row0 + t) * (d + 4) + i] = xs;
             };
-            if (stage && !quad) {                           // dx = -grad_p H = -p
-                for (int t = 0; t < T; ++t)
-                    for (int i = c.tid; i < d; i += c.nthreads) rk(t, i, -G[t * pl.GLD + i]);
+            if (stage && !quad) {                           // dx = -grad_p H = -p, all T*d components in one flat sweep
+                for (int j = c.tid; j < T * d; j += c.nthreads) {
+                    int t = 0, i = j;
+                    while (i >= d) { i -= d; ++t; }
+                    rk(t, i, -G[t * pl.GLD + i]);
+                }
             }
             physics_sums(c, pl, pb);                        // ends with a barrier
             STAMP(c, 8);
@@ -1215,7 +1229,6 @@ __global__ void __launch_bounds__(512) prob_kernel(DevPlan pl, DevProb pb, const
     const long row0 = (long)blockIdx.x * T;
     for (int i = c.tid; i < pl.ldsFloats; i += c.nthreads) lds[i] = 0.f;
     __syncthreads();
-    build_pair_table(c, pl, pb);
     for (int t = 0; t < T; ++t) {
         long row = row0 + t; if (row >= n) row = n - 1;
         for (int i = c.tid; i < d; i += c.nthreads) {
@@ -1305,7 +1318,7 @@ static int make_group_plan(const DevPlan& base, int n_agents, int kind /* NOCF_P
     gp.LDg = rup(std::max(base.KQm * 4, base.m), 64) + 4;
     gp.LDy = 68;
     const int L = gp.L, TG = GK_TG, OWN = gp.OWN;
-    const int npairs = (n_agents * (n_agents - 1)) / 2;
+    (void)n_agents;
     int l = 0;
     auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
     gp.lR1 = take(std::max(TG * base.LDs, 4 * TG * 64));
@@ -1325,7 +1338,7 @@ static int make_group_plan(const DevPlan& base, int n_agents, int kind /* NOCF_P
     pl.lPHI = take(OWN);
     const bool maybe_quad = (kind < 0 || kind == NOCF_PROB_QUADCOPTER);
     pl.lTRIG = take(maybe_quad ? OWN * std::max(1, n_agents) * 6 : 4);
-    pl.lPT = take((kind != NOCF_PROB_QUADCOPTER && n_agents > 2) ? npairs + 1 : 4);
+    pl.lPT = take(4);
     take(64);
     pl.ldsFloats = l;
     if ((size_t)l * 4 > 80 * 1024) return NOCF_E_LDS;          // two workgroups per CU must fit

@@ -19,8 +19,8 @@ POINTS = {0: "eval entry", 1: "z=As done", 8: "open: entry", 9: "open: acts in r
           3: "fwd: barrier passed", 24: "bwd: entry", 25: "bwd: acts in regs", 26: "bwd: stream end", 27: "bwd: epilogue end",
           4: "bwd: barrier passed", 32: "close: entry", 33: "close: acts in regs", 34: "close: stream end",
           35: "close: partials written", 36: "close: split barrier", 37: "close: epilogue end", 5: "close: barrier passed",
-          40: "physics: sums done", 41: "physics: reduce barrier", 42: "RK: sweep done", 43: "RK: finish done", 44: "RK: barrier passed"}
-ORDER = [0, 1, 8, 9, 10, 11, 2, 16, 17, 18, 19, 3, 24, 25, 26, 27, 4, 32, 33, 34, 35, 36, 37, 5, 40, 41, 42, 43, 44]
+          6: "physics: entry (sweep done)", 7: "physics: p^2 done", 14: "physics: obstacle done", 40: "physics: sums done", 41: "physics: reduce barrier", 42: "RK: sweep done", 43: "RK: finish done", 44: "RK: barrier passed"}
+ORDER = [0, 1, 8, 9, 10, 11, 2, 16, 17, 18, 19, 3, 24, 25, 26, 27, 4, 32, 33, 34, 35, 36, 37, 5, 6, 7, 14, 40, 41, 42, 43, 44]
 
 
 def main():
