@@ -63,10 +63,11 @@ struct DevPlan {
     int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD, lSCB, lUB;   // adjoint
     int pMB, pKQc;                   // column blocks per hidden phase / k-quads of the closing phase (diagnostic: halves)
     int ldsFloats;
-    int pad_;                        // keeps the struct free of implicit padding (plans are compared with memcmp)
+    int lPW;                         // x-only cost partials formed in the shadow of the residual phases: [T][2 waves][2]
 };
 
 static_assert(sizeof(DevPlan) % 4 == 0 && sizeof(DevPlan) / 4 <= 256, "plan copy is done by one 256-thread block");
+static_assert(sizeof(DevPlan) == 4 * 58 + 8 * 11, "no implicit padding: plans are compared with memcmp");
 
 // ------------------------------------------------------------------------------------------
 // plan layout.  constexpr: the host builds the plan of any shape at run time; for the shapes named in
@@ -159,6 +160,7 @@ constexpr int plan_layout(int d, int m, int nTh, int r, int n_agents, int bwd, i
         pl.lPHI = l; l += rup(T, 4);
         pl.lTRIG = l; l += rup(T * imax(1, n_agents) * 6, 4);
         pl.lPT = l; l += 4;                                         // (spare)
+        pl.lPW = l; l += rup(T * 4, 4);
         pl.nVEC = (int)(pl.oPlan - pl.ob0);
         pl.lVEC = l; l += rup(pl.nVEC, 4);
         if (bwd) {
@@ -444,9 +446,17 @@ __device__ __forceinline__ float part_sum(const float* part, int pstride, int SK
 // SK == 1: the wave that owns a column block applies epi straight from its accumulators.
 // SK  > 1: split-K partials go through LDS (fixed-order sum, deterministic); contains one barrier.
 // The caller puts a barrier after the call before anyone reads what epi wrote.
-template <int S, class Epi>
+struct NoPost { __device__ __forceinline__ void operator()() const {} };
+
+// post(): runs on every wave after its own units and epilogues, before the caller's barrier -- work placed there
+// fills the time a wave that finished streaming early would otherwise spend waiting for the slowest one
+struct NoIdle { __device__ __forceinline__ void operator()(int, int) const {} };
+
+// idle(i, n): runs on the waves that own no unit of this phase (wave i of n such waves) while the others stream
+template <int S, class Epi, class Post = NoPost, class Idle = NoIdle>
 __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring& rg, bool pre, const PhaseDesc& ph,
-                                           const PhaseDesc& nxt, int act_off, int ld, Epi epi, int stamp_id = 11) {
+                                           const PhaseDesc& nxt, int act_off, int ld, Epi epi, int stamp_id = 11, Post post = Post(),
+                                           Idle idle = Idle()) {
     const int partLD = ph.nblk * 64;
     const int pstride = pl.T * partLD;
     const int units = ph.nblk * ph.SK;
@@ -515,6 +525,8 @@ __device__ __forceinline__ void gemm_phase(const Ctx& c, const DevPlan& pl, Ring
         }
     }
     if (want_next && !next_done) ring_preload(c, rg, nxt, c.wave);     // waves without a unit in this phase
+    if (c.wave >= units) idle(c.wave - units, pl.nwaves - units);
+    post();
     TL(c, tlb + 3);
     if (ph.SK > 1) {
         __syncthreads();
@@ -569,9 +581,49 @@ __device__ __forceinline__ void load_vectors(const Ctx& c, const DevPlan& pl) {
 // src/Phi.py:99-138 restated per sample row; results: G[t][0..d]; if need_value PHI[t]=Phi(s).
 // Every thread of the workgroup must call it (it contains barriers).
 // ------------------------------------------------------------------------------------------
-template <int S>
+// z = A s for the T samples in SB (the low-rank quadratic's inner product; A is at most 16 x (d+1)), by the `nth`
+// threads numbered tid_i: 8 lanes share a row; four strided products per turn so the LDS reads go out together.
+// Every caller accumulates in the same order, so the value does not depend on who computes it.
+__device__ __forceinline__ void z_from_s(const DevPlan& pl, int tid_i, int nth) {
+    const int T = pl.T, r = pl.r, D1 = pl.D1;
+    const float* Araw = lds + pl.lVEC - pl.ob0 + pl.oA;
+    const int items = T * r * 8;
+    for (int base = 0; base < items; base += nth) {
+        const int id = base + tid_i;
+        const int part = id & 7, tr = id >> 3;
+        float acc = 0.f;
+        if (id < items) {
+            const int t = tr / r, rr = tr - t * r;
+            const float* arow = Araw + rr * D1;
+            const float* srow = lds + pl.lSB + t * pl.LDs;
+            for (int i = part; i < D1; i += 32) {
+                float av[4], sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int iu = i + 8 * u;
+                    const int ic = iu < D1 ? iu : D1 - 1;
+                    av[u] = iu < D1 ? arow[ic] : 0.f;
+                    sv[u] = srow[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += av[u] * sv[u];
+            }
+        }
+        acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 1);
+        if (id < items && part == 0) { const int t = tr / r; lds[pl.lZQ + t * ZQLD + (tr - t * r)] = acc; }
+    }
+}
+
+struct NoShadow { __device__ __forceinline__ void operator()(int) const {} };
+
+// shadow(k): extra work of the caller run by every wave at the end of the last forward residual phase (k = 0) and
+// of the first backward residual phase (k = 1), i.e. while the slower waves of those long phases still stream
+template <int S, class Shadow = NoShadow>
 __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring& rg, bool& ring_ready, bool more_evals,
-                         bool z_ready = false /* z = A s already sits in ZQ (the rollout's RK tail computed it) */) {
+                         bool z_ready = false /* z = A s already sits in ZQ (the rollout's RK tail computed it) */,
+                         Shadow shadow = Shadow()) {
     const int T = pl.T, LD = pl.LD, m = pl.m, D1 = pl.D1, r = pl.r;
     const int oSB = pl.lSB, oTH = pl.lTH, oAV = pl.lAV, oG = pl.lG, oZQ = pl.lZQ;
     const float hN = pl.hN;
@@ -593,24 +645,11 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
     TL(c, 0);
     // the opening weights do not wait for z: start them first (unless the previous evaluation already did)
     if (!ring_ready && c.wave < phOpen.nblk * phOpen.SK) ring_preload(c, rg, phOpen, c.wave);
-    // ---- z = A s (the low-rank quadratic's inner product; A is at most 10 x (d+1)).  8 lanes share a row.
-    if (!z_ready) {
-        const int items = T * r * 8;
-        for (int base = 0; base < items; base += c.nthreads) {
-            const int id = base + c.tid;
-            const int part = id & 7, tr = id >> 3;
-            float acc = 0.f;
-            if (id < items) {
-                const int t = tr / r, rr = tr - t * r;
-                const float* arow = Araw + (long)rr * D1;
-                for (int i = part; i < D1; i += 8) acc += arow[i] * lds[oSB + t * pl.LDs + i];
-            }
-            acc += __shfl_xor(acc, 4);
-            acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 1);
-            if (id < items && part == 0) { const int t = tr / r; lds[oZQ + t * ZQLD + (tr - t * r)] = acc; }
-        }
-    }
+    // ---- z = A s: needed by the closing epilogue (and by Phi itself).  When the closing phase leaves waves without
+    // a unit they compute it there, beside the weight stream; otherwise, or when Phi is wanted, it is done here.
+    const int closeUnits = pl.DB * pl.SK6;
+    const bool z_in_closing = closeUnits < pl.nwaves && pl.SK6 > 1 && !need_value;   // (the split-K barrier orders it before the epilogue)
+    if (!z_ready && !z_in_closing) z_from_s(pl, c.tid, c.nthreads);
     TL(c, 1);
     // ---- opening layer: o = s K0^T + b0 ; u0 = sigma(o) ; gate0 = tanh(o)
     gemm_phase<S>(c, pl, rg, true, phOpen, phFwd(1), oSB, pl.LDs, [&](int t, int col, float v) {
@@ -653,7 +692,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
                     if (need_value) lds[oUn + t * LD + col] = lds[oUc + t * LD + col] + hN * sigma_act(q);
                 }
             }
-        }, 3);
+        }, 3, [&]() { if (i == lastLayer) shadow(0); });
         __syncthreads();
     }
     TL(c, 3);
@@ -683,7 +722,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
                 lds[oAn + t * LD + col] = a;
                 lds[oVn + t * LD + col] = lds[oTHp + t * LD + col] * a;
             }
-        }, 5);
+        }, 5, [&]() { if (i == lastLayer) shadow(1); });
         __syncthreads();
     }
     TL(c, 4);
@@ -700,7 +739,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
             for (int q = 0; q < ZQLD; ++q) g = fmaf(aq[q], zq[q], g);
             lds[oG + t * pl.GLD + i] = g;
         }
-    }, 7);
+    }, 7, NoPost(), [&](int iw, int niw) { if (z_in_closing && !z_ready) z_from_s(pl, iw * 64 + c.lane, niw * 64); });
     ring_ready = more_evals;
     __syncthreads();
     TL(c, 5);
@@ -821,9 +860,40 @@ __device__ __forceinline__ float pair_sum_cyclic(const float* __restrict__ x, in
     return w;
 }
 
+// The x-only part of the running costs (obstacle sum, interaction sum) of sample t = 2*k + (wave >> 1), formed by
+// waves 0..3 (two per sample) at the end of residual phase k (0: forward, 1: backward) of an 8-wave, 4-sample
+// workgroup: those are the first waves of their SIMDs and finish streaming well before the second ones, so this runs
+// while the phase is still waiting for its slowest wave.  Partials go to PW[t][wave & 1][0..1].
+__device__ __forceinline__ void physics_x_shadow(const Ctx& c, const DevPlan& pl, const DevProb& pb, int k) {
+    if (c.wave >= 4) return;
+    const int N = pb.nAgents;
+    const int t = 2 * k + (c.wave >> 1), half = c.wave & 1;
+    const int j0 = half * 64 + c.lane;
+    const float* x = lds + pl.lSB + t * pl.LDs;
+    const bool wantW = want_W(pb);
+    const float den = (float)(2.0 * pb.r * pb.r);
+    const double fac = pb.training ? (pb.kind == NOCF_PROB_SWARMTRAJ ? 3.2 : 2.2) : 2.0;
+    const float thr = (float)(fac * pb.r);
+    const float thr2 = thr * thr * 1.000002f;
+    float vq = 0.f, vw = 0.f;
+    if (pb.kind == NOCF_PROB_CROSS2D) {
+        if (pb.obstacle != NOCF_OBS_NONE)
+            for (int a = j0; a < N; a += 128) vq += obstacle_cross2d(pb, x[2 * a], x[2 * a + 1]);
+        if (wantW) vw = pair_sum_cyclic<2>(x, N, j0, 128, thr, thr2, den);
+    } else {
+        if (pb.obstacle != NOCF_OBS_NONE && pb.alphQ > 0.0)
+            for (int a = j0; a < N; a += 128) vq += obstacle_swarm(pb, x[3 * a], x[3 * a + 1], x[3 * a + 2]);
+        if (wantW) vw = pair_sum_cyclic<3>(x, N, j0, 128, thr, thr2, den);
+    }
+    for (int off = 32; off > 0; off >>= 1) { vq += __shfl_xor(vq, off); vw += __shfl_xor(vw, off); }
+    if (c.lane == 0) { lds[pl.lPW + t * 4 + half * 2] = vq; lds[pl.lPW + t * 4 + half * 2 + 1] = vw; }
+}
+
 // Phase 1 (all threads): per-sample partial sums -> RED (ends with a barrier).
 //   v0 = sum p^2, v1 = raw obstacle sum, v2 = raw interaction sum; quadcopter: sin/cos table.
-__device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb) {
+// x_pre: the x-only terms (obstacle and interaction sums) were already formed in the shadow of the residual phases
+// (physics_x_shadow); only sum p^2 is computed here and the partials are folded in.
+__device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb, bool x_pre = false) {
     float* Lm = lds;
     const float* X = Lm + pl.lSB;
     const float* P = Lm + pl.lG;
@@ -838,7 +908,9 @@ __device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb)
     TL(c, 6);
     for (int i = j0; i < d; i += Gsz) v[0] += p[i] * p[i];
     TL(c, 7);
-    if (pb.kind == NOCF_PROB_CROSS2D) {
+    if (x_pre) {
+        if (j0 == 0) { v[1] = Lm[pl.lPW + t * 4] + Lm[pl.lPW + t * 4 + 2]; v[2] = Lm[pl.lPW + t * 4 + 1] + Lm[pl.lPW + t * 4 + 3]; }
+    } else if (pb.kind == NOCF_PROB_CROSS2D) {
         if (pb.obstacle != NOCF_OBS_NONE)
             for (int a = j0; a < N; a += Gsz) v[1] += obstacle_cross2d(pb, x[2 * a], x[2 * a + 1]);
     } else if (pb.kind == NOCF_PROB_SWARMTRAJ) {
@@ -846,7 +918,7 @@ __device__ void physics_sums(const Ctx& c, const DevPlan& pl, const DevProb& pb)
             for (int a = j0; a < N; a += Gsz) v[1] += obstacle_swarm(pb, x[3 * a], x[3 * a + 1], x[3 * a + 2]);
     }
     TL(c, 14);
-    if (want_W(pb) && N >= 2) {
+    if (!x_pre && want_W(pb) && N >= 2) {
         const float den = (float)(2.0 * pb.r * pb.r);
         const int pd = (pb.kind == NOCF_PROB_CROSS2D) ? 2 : 3;      // position components per agent
         if (N == 2) {
@@ -1034,7 +1106,11 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
 #ifdef NOCF_STAMPS
             c.tl = (ra.stamps && blockIdx.x == 7 && k == 40 && st == 1) ? ra.stamps + (long)gridDim.x * 12 : nullptr;
 #endif
-            phi_eval<S>(c, pl, fin, rg, ring_ready, false, z_next_ready);
+            // point agents, N > 2, 8 waves x 4 samples, one residual layer: the x-only cost terms are formed in the
+            // shadow of the two long phases (physics_x_shadow)
+            const bool xpre = !fin && !quad && pb.nAgents > 2 && pl.nwaves == 8 && pl.T == 4 && pl.nTh == 2;
+            phi_eval<S>(c, pl, fin, rg, ring_ready, false, z_next_ready,               // (one call site: see nocf_bwd.inc)
+                        [&](int k2) { if (xpre) physics_x_shadow(c, pl, pb, k2); });
             z_next_ready = false;
             if (fin) break;
             // ---- RK update (src/OCflow.py:143-184): z_next accumulates, SB receives the next stage state
@@ -1069,7 +1145,7 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
                     rk(t, i, -G[t * pl.GLD + i]);
                 }
             }
-            physics_sums(c, pl, pb);                        // ends with a barrier
+            physics_sums(c, pl, pb, xpre);                  // ends with a barrier
             STAMP(c, 8);
             if (stage) {
                 if (!quad) {
@@ -1079,7 +1155,7 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
                     // into SB.  z is left to phi_eval when the next evaluation is not a plain stage.
                     const int fw = pl.nwaves - 1;
                     const bool split = pl.nwaves > 1;
-                    const bool zpre = !(last && (k == ra.nt - 1 || ra.zFull));
+                    const bool zpre = !(last && (k == ra.nt - 1 || ra.zFull)) && !(pl.DB * pl.SK6 < pl.nwaves && pl.SK6 > 1);
                     if (c.wave == fw && c.lane < 4 * T) {
                         const int s = c.lane >> 2, q = c.lane & 3;
                         const Costs cs = physics_finish(c, pl, pb, s);
