@@ -1079,6 +1079,7 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
     Ring rg;
     bool ring_ready = false;
     bool z_next_ready = false;                      // ZQ already holds A s of the coming evaluation
+    float costZ0 = 0.f, costZA = 0.f;               // point agents: cost integrals of lane (sample, component) of the last wave
     double tk = ra.t0;
     const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
     const int nsub = nstage + (ra.zFull ? 1 : 0);
@@ -1160,7 +1161,19 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
                         const int s = c.lane >> 2, q = c.lane & 3;
                         const Costs cs = physics_finish(c, pl, pb, s);
                         const float val = (q == 0) ? cs.L : (q == 1) ? fabsf(G[s * pl.GLD + d] - cs.H) : (q == 2) ? cs.Q : cs.W;
-                        rk(s, d + q, val);
+                        // the running cost integrals of this lane's (sample, component) live in two registers for the
+                        // whole rollout (costZ0 = z0 part, costZA = RK accumulator): no LDS read-modify-write chain
+                        {
+                            const float K = hs * val;
+                            float xs;
+                            if (nstage == 1) { xs = costZ0 + K; costZ0 = xs; }
+                            else if (st == 0) { costZA = costZ0 + c16 * K; xs = costZ0 + 0.5f * K; }
+                            else if (st == 1) { costZA += c26 * K; xs = costZ0 + 0.5f * K; }
+                            else if (st == 2) { costZA += c26 * K; xs = costZ0 + K; }
+                            else { xs = costZA + c16 * K; costZ0 = xs; }
+                            if (last && ra.zFull && row0 + s < ra.n)
+                                ra.zFull[((long)(k + 1) * ra.n + row0 + s) * (d + 4) + d + q] = xs;
+                        }
                         if (q == 0) SB[s * pl.LDs + d] = (float)tnext;
                     }
                     if (!split || c.wave != fw) {
@@ -1222,6 +1235,10 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
         for (int i = 0; i < 12; ++i) ra.stamps[(long)blockIdx.x * 12 + i] = c.acc[i];
 #endif
 
+    if (!quad) {                                    // the cost integrals return from their registers
+        if (c.wave == pl.nwaves - 1 && c.lane < 4 * T) Z0[(c.lane >> 2) * ZLD + d + (c.lane & 3)] = costZ0;
+        __syncthreads();
+    }
     // ---- terminal costs (src/OCflow.py:58-76)
     {
         const int Gsz = c.nthreads / T;
