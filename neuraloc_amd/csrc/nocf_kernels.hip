@@ -1394,8 +1394,12 @@ static int env_int(const char* name, int dflt) {
 
 // host wrapper: geometry knobs from the environment, then the (constexpr) layout
 static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, int bwd = 0) {
-    return plan_layout(d, m, nTh, r, n_agents, bwd, env_int("NOCF_NWAVES", 0), env_int("NOCF_SUBTILES", 0),
-                       env_int("NOCF_DIAG_HALF", 0), *out);
+#ifdef NOCF_STAMPS
+    const int diagHalf = env_int("NOCF_DIAG_HALF", 0);    // diagnostic builds only: a timing experiment with wrong results
+#else
+    const int diagHalf = 0;
+#endif
+    return plan_layout(d, m, nTh, r, n_agents, bwd, env_int("NOCF_NWAVES", 0), env_int("NOCF_SUBTILES", 0), diagHalf, *out);
 }
 
 // Group (weight-sliced) plan: returns 0 and fills *out when the shape qualifies, else an NOCF_E_* code.

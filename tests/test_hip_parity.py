@@ -483,3 +483,34 @@ def test_backward_two_quadcopters_with_interaction():
         scale = w.abs().max().item()
         err = (p.grad.cpu().double() - w).abs().max().item()
         assert err <= 2e-4 * scale + 1e-6, f"{k}: err {err:g} at scale {scale:g}"
+
+
+@pytest.mark.parametrize("name", ["swarm50", "singlequad"])
+def test_specialised_and_generic_instantiations_agree(name, monkeypatch):
+    """the shape-specialised kernel (compile-time plan) and the generic one (plan read from the workspace) are the
+    same arithmetic in the same order: per-sample tables, trajectories, controls and parameter gradients agree to ulps"""
+    from conftest import load_golden
+    g = load_golden(name)
+    alph, nt = g.meta["alph"], 10
+    x = g.t("x").to(DEV)
+    out = {}
+    for fixed in ("1", "0"):
+        monkeypatch.setenv("NOCF_FIXED", fixed)
+        net = make_net(g, DEV)
+        prob = make_prob(g, DEV, training=False)
+        with torch.no_grad():
+            _, csn = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph, noMean=True)
+            zF, cF = na.OCflow(x[:7], net, prob, [0.0, 1.0], nt, "rk4", alph, intermediates=True)
+        net.train(); prob.train()
+        Jc, _ = na.OCflow(x[:12].contiguous(), net, prob, [0.0, 1.0], 6, "rk4", alph)
+        Jc.backward()
+        out[fixed] = (torch.cat(csn, 1).cpu(), zF.cpu(), cF.cpu(), Jc.item(),
+                      torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu())
+    a, b = out["1"], out["0"]
+    # same source, two instantiations: the compiler may contract a*b+c differently once strides are literals, so the
+    # comparison allows a few ulps (swarm50 comes out bit-identical, singlequad differs in the last bits)
+    for u, v in zip(a[:3], b[:3]):
+        assert (u - v).abs().max().item() <= 2e-6 * v.abs().max().item()
+    assert abs(a[3] - b[3]) <= 2e-6 * abs(b[3])
+    scale = b[4].abs().max().item()
+    assert (a[4] - b[4]).abs().max().item() <= 2e-6 * scale
