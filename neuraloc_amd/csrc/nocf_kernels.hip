@@ -195,10 +195,14 @@ struct FixedPlan {
     static constexpr bool fixed = true;
     static constexpr DevPlan make() { DevPlan p{}; (void)plan_layout(D, M, NTH, R, NAG, BWD, 0, 0, 0, p); return p; }
 };
-// shapes with a specialised instantiation: (d, m, nTh, r, agents) of BASELINE.json's tile-kernel configurations
-#define FIXED_SHAPES(X) X(150, 512, 2, 10, 50) X(12, 128, 2, 10, 1)
-// the small BASELINE shapes: evaluation takes the lane kernel, TRAINING (record + adjoint) takes the tile kernels
-#define FIXED_SHAPES_TRAIN(X) X(4, 16, 2, 5, 2) X(4, 32, 2, 5, 2) X(24, 32, 2, 10, 12)
+// shapes with a specialised instantiation: (d, m, nTh, r, agents).  First the BASELINE.json tile-kernel configurations
+// (swarm50, singlequad), then the initProb problems whose d+1 exceeds the lane kernel's 32 at the reference's default
+// width m = 32 (midcross20, midcross30, swarm).
+#define FIXED_SHAPES(X) X(150, 512, 2, 10, 50) X(12, 128, 2, 10, 1) X(40, 32, 2, 10, 20) X(60, 32, 2, 10, 30) X(96, 32, 2, 10, 32)
+// small shapes: evaluation takes the lane kernel, TRAINING (record + adjoint) takes the tile kernels -- the other
+// BASELINE configs (swap2, softcorridor = midcross2 = swap12_1pair, swap12) and the remaining initProb problems at m = 32
+#define FIXED_SHAPES_TRAIN(X) X(4, 16, 2, 5, 2) X(4, 32, 2, 5, 2) X(24, 32, 2, 10, 12) \
+    X(8, 32, 2, 9, 4) X(12, 32, 2, 10, 6) X(16, 32, 2, 10, 8) X(20, 32, 2, 10, 10)
 
 template <class SP>
 static bool plan_is(const DevPlan& run) {

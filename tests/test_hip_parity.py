@@ -514,3 +514,32 @@ def test_specialised_and_generic_instantiations_agree(name, monkeypatch):
     assert abs(a[3] - b[3]) <= 2e-6 * abs(b[3])
     scale = b[4].abs().max().item()
     assert (a[4] - b[4]).abs().max().item() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("name", ["midcross4", "midcross20", "midcross30", "swarm", "swap12_3pair", "swap12_4pair", "swap12_5pair"])
+def test_specialised_default_width_shapes_agree_with_generic(name, monkeypatch):
+    """the initProb problems at the reference's default width (m = 32, nTh = 2) have specialised tile-kernel
+    instantiations (evaluation when d+1 > 32, record + adjoint for all): same results as the generic instantiation"""
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(3)
+    prob, x0, _, _ = na.initProb(name, 20, 20, 0.5, alph, lambda t: t.float().to(DEV))
+    d = x0.shape[1]
+    sd = _synth_state_dict(2, 32, d, seed=len(name))
+    out = {}
+    for fixed in ("1", "0"):
+        monkeypatch.setenv("NOCF_FIXED", fixed)
+        monkeypatch.setenv("NOCF_LANE", "0")                 # the tile kernels, also where the lane kernel would qualify
+        net = na.Phi(nTh=2, m=32, d=d, alph=alph)
+        net.load_state_dict(sd)
+        net = net.to(DEV)
+        prob.eval()
+        with torch.no_grad():
+            _, csn = na.OCflow(x0, net, prob, [0.0, 1.0], 6, "rk4", alph, noMean=True)
+        net.train(); prob.train()
+        Jc, _ = na.OCflow(x0, net, prob, [0.0, 1.0], 6, "rk4", alph)
+        Jc.backward()
+        out[fixed] = (torch.cat(csn, 1).cpu(), Jc.item(), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu())
+    a, b = out["1"], out["0"]
+    assert (a[0] - b[0]).abs().max().item() <= 2e-6 * b[0].abs().max().item()
+    assert abs(a[1] - b[1]) <= 2e-6 * abs(b[1])
+    assert (a[2] - b[2]).abs().max().item() <= 2e-6 * b[2].abs().max().item()
