@@ -62,7 +62,10 @@ typedef struct NocfPhi {
     const float* w;     /* device [m]                                                 */
     const float* A;     /* device [r, d+1]                                            */
     const float* cw;    /* device [d+1]                                               */
-    float cb;
+    float cb;           /* c.bias as a host value (used when cb_dev is NULL)          */
+    const float* cb_dev;/* optional: device address of c.bias; when set the kernels   */
+                        /* read the bias there and the caller needs no device-to-host */
+                        /* copy (a synchronisation per call) to fill `cb`             */
 } NocfPhi;
 
 /* One problem object (the attributes the reference's calcLHQW/calcGradpH/calcCtrls read). */
@@ -123,6 +126,13 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob,
                      float* z_out, float* persample, float* cost_sums,
                      float* zFull, float* ctrlFull,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The last lines of OCflow (src/OCflow.py:80-90): out[0..6] = cost_sums[0..6] / cost_sums[7] (the batch means
+ * [L, G, HJt, HJfin, HJgrad, Q, W]) and out[7] = Jc = L + alph[0] G + alph[3] HJt + alph[4] HJfin + alph[5] HJgrad.
+ * cost_sums is what nocf_rollout_f32 wrote (after the all-reduce when the batch is sharded).  alph: host [6].
+ */
+int nocf_cost_means_f32(const float* cost_sums, const float* alph, float* out, void* stream);
 
 /*
  * Training: the pair below replaces `Jc = OCflow(...); Jc.backward()` of trainOC.py:172-173

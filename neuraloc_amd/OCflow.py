@@ -64,7 +64,16 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
 
 def costs_from_sums(sums, alph):
     """means of the 7 cost terms and Jc from the kernel's 8 sums (7 column sums + count).
-    cs order is [L, G, HJt, HJfin, HJgrad, Q, W]; G is un-weighted (src/OCflow.py:80-90)."""
+    cs order is [L, G, HJt, HJfin, HJgrad, Q, W]; G is un-weighted (src/OCflow.py:80-90).
+    On the device this is one tiny launch (nocf_cost_means_f32); host tensors (the gloo tests' injected sums) take
+    the same formula in torch."""
+    if sums.is_cuda:
+        out = torch.empty(8, dtype=torch.float32, device=sums.device)
+        alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+        with torch.cuda.device(sums.device):
+            rc = _lib.lib().nocf_cost_means_f32(_lib.ptr(sums), alph_c, _lib.ptr(out), _lib.stream_ptr(sums.device))
+        _lib.check(rc, "nocf_cost_means_f32")
+        return out[7], [out[i] for i in range(7)]
     means = sums[:7] / sums[7]
     cs = [means[i] for i in range(7)]
     Jc = cs[0] + alph[0] * cs[1] + alph[3] * cs[2] + alph[4] * cs[3] + alph[5] * cs[4]

@@ -92,7 +92,8 @@ class Phi(nn.Module):
         st.w = dv(self.w.weight, "w.weight")
         st.A = dv(self.A, "A")
         st.cw = dv(self.c.weight, "c.weight")
-        st.cb = float(self.c.bias.detach().cpu().item())
+        st.cb = 0.0
+        st.cb_dev = dv(self.c.bias, "c.bias")           # read on the device: no device-to-host copy (a sync) per call
         nbytes = _lib.lib().nocf_rollout_workspace_bytes(self.d, self.m, self.nTh, int(n))
         if nbytes == 0:
             raise RuntimeError("nocf_workspace_bytes: unsupported (d, m, nTh)")

@@ -23,7 +23,7 @@ fp = C.POINTER(C.c_float)
 class NocfPhi(C.Structure):
     _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("nTh", C.c_int32), ("r", C.c_int32),
                 ("K0", C.c_void_p), ("b0", C.c_void_p), ("K", C.c_void_p), ("b", C.c_void_p),
-                ("w", C.c_void_p), ("A", C.c_void_p), ("cw", C.c_void_p), ("cb", C.c_float)]
+                ("w", C.c_void_p), ("A", C.c_void_p), ("cw", C.c_void_p), ("cb", C.c_float), ("cb_dev", C.c_void_p)]
 
 
 class NocfProb(C.Structure):
@@ -57,6 +57,8 @@ def lib():
                                    C.c_double, C.c_double, C.c_int32, C.c_int32, fp,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]
+    L.nocf_cost_means_f32.restype = C.c_int
+    L.nocf_cost_means_f32.argtypes = [C.c_void_p, fp, C.c_void_p, C.c_void_p]
     L.nocf_rollout_record_f32.restype = C.c_int
     L.nocf_rollout_record_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_void_p, C.c_int64,
                                           C.c_double, C.c_double, C.c_int32, C.c_int32, fp,

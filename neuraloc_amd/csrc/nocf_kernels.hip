@@ -220,6 +220,7 @@ struct DevProb {
 
 struct DevPhi {
     const float *K0, *b0, *K, *b, *w, *A, *cw;
+    const float* cbp;                // device address of c.bias, or null (then the plan carries the host value)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -297,7 +298,9 @@ __global__ void pack_kernel(DevPlan pl, DevPhi P, float* __restrict__ ws) {
     // the plan itself, for the kernels that read it through a pointer
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DevPlan) / 4) {
         const unsigned* src = reinterpret_cast<const unsigned*>(&pl);
-        reinterpret_cast<unsigned*>(ws + pl.oPlan)[threadIdx.x] = src[threadIdx.x];
+        unsigned v = src[threadIdx.x];
+        if (P.cbp && threadIdx.x == offsetof(DevPlan, cb) / 4) v = __float_as_uint(*P.cbp);
+        reinterpret_cast<unsigned*>(ws + pl.oPlan)[threadIdx.x] = v;
     }
 }
 
@@ -329,6 +332,39 @@ __device__ __forceinline__ void act_pair(float o, float& sig, float& th) {
 __device__ __forceinline__ float tanh_fast(float o) {
     const float e = __builtin_amdgcn_exp2f(fabsf(o) * -2.885390081777927f);
     return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), o);
+}
+
+// ------------------------------------------------------------------------------------------
+// lane reductions on the DPP path (VALU operand swizzles, a few cycles each) instead of __shfl_xor, which hipcc turns
+// into ds_bpermute_b32: an LDS round trip (>100 cycles) per step of a dependent chain.
+//   quad_perm [1,0,3,2] = lane^1, [2,3,0,1] = lane^2, row_half_mirror = 7-i within 8 lanes, row_mirror = 15-i within 16
+// After k steps every lane of an aligned 2^k group holds the group's sum (fixed order: deterministic).
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_peer(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum2(float v) { return v + dpp_peer<0xB1>(v); }
+__device__ __forceinline__ float sum4(float v) { v = sum2(v); return v + dpp_peer<0x4E>(v); }
+__device__ __forceinline__ float sum8(float v) { v = sum4(v); return v + dpp_peer<0x141>(v); }
+__device__ __forceinline__ float sum16(float v) { v = sum8(v); return v + dpp_peer<0x140>(v); }
+// all 64 lanes (every lane must be active): the four row totals meet through scalar registers
+__device__ __forceinline__ float sum64(float v) {
+    v = sum16(v);
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+// aligned groups of seg = 2, 4, ..., 64 lanes
+__device__ __forceinline__ float sum_seg(float v, int seg) {
+    if (seg >= 64) return sum64(v);
+    if (seg >= 2) v += dpp_peer<0xB1>(v);
+    if (seg >= 4) v += dpp_peer<0x4E>(v);
+    if (seg >= 8) v += dpp_peer<0x141>(v);
+    if (seg >= 16) v += dpp_peer<0x140>(v);
+    if (seg >= 32) v += __shfl_xor(v, 16);            // (no 32-lane DPP pattern on gfx9: one crossbar step)
+    return v;
 }
 
 struct Ctx {
@@ -552,10 +588,8 @@ template <int NV>
 __device__ __forceinline__ void group_reduce(const Ctx& c, const DevPlan& pl, float (&v)[NV]) {
     const int G = c.nthreads / pl.T;
     const int seg = G < 64 ? G : 64;
-    for (int off = seg >> 1; off > 0; off >>= 1) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], off);
-    }
+    for (int i = 0; i < NV; ++i) v[i] = sum_seg(v[i], seg);
     float* red = lds + pl.lRED;
     if ((c.tid & (seg - 1)) == 0) {
         const int subseg = c.tid / seg;
@@ -613,9 +647,7 @@ __device__ __forceinline__ void z_from_s(const DevPlan& pl, int tid_i, int nth) 
                 for (int u = 0; u < 4; ++u) acc += av[u] * sv[u];
             }
         }
-        acc += __shfl_xor(acc, 4);
-        acc += __shfl_xor(acc, 2);
-        acc += __shfl_xor(acc, 1);
+        acc = sum8(acc);
         if (id < items && part == 0) { const int t = tr / r; lds[pl.lZQ + t * ZQLD + (tr - t * r)] = acc; }
     }
 }
@@ -889,7 +921,7 @@ __device__ __forceinline__ void physics_x_shadow(const Ctx& c, const DevPlan& pl
             for (int a = j0; a < N; a += 128) vq += obstacle_swarm(pb, x[3 * a], x[3 * a + 1], x[3 * a + 2]);
         if (wantW) vw = pair_sum_cyclic<3>(x, N, j0, 128, thr, thr2, den);
     }
-    for (int off = 32; off > 0; off >>= 1) { vq += __shfl_xor(vq, off); vw += __shfl_xor(vw, off); }
+    vq = sum64(vq); vw = sum64(vw);
     if (c.lane == 0) { lds[pl.lPW + t * 4 + half * 2] = vq; lds[pl.lPW + t * 4 + half * 2 + 1] = vw; }
 }
 
@@ -1196,9 +1228,7 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
                                     const float* arow = vecA + (long)rr * D1;
                                     for (int i = part; i < D1; i += 8) acc += arow[i] * ((i < d) ? XN[t * ZLD + i] : tn);
                                 }
-                                acc += __shfl_xor(acc, 4);
-                                acc += __shfl_xor(acc, 2);
-                                acc += __shfl_xor(acc, 1);
+                                acc = sum8(acc);
                                 if (id < items && part == 0) { const int t = tr / r; lds[pl.lZQ + t * ZQLD + (tr - t * r)] = acc; }
                             }
                         }
@@ -1372,6 +1402,17 @@ __global__ void __launch_bounds__(256) cost_sum_kernel(const float* __restrict__
     if (threadIdx.x == 7) out[7] = (err && *err) ? __int_as_float(0x7fc00000) : (float)n;
 }
 
+// means of the 7 cost terms and Jc from the 8 sums, one launch instead of a dozen tiny elementwise ones
+__global__ void cost_means_kernel(const float* __restrict__ sums, float a0, float a3, float a4, float a5, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < 7) out[i] = sums[i] / sums[7];
+    if (i == 7) {
+        const float n = sums[7];
+        const float L = sums[0] / n, G = sums[1] / n, HJt = sums[2] / n, HJfin = sums[3] / n, HJgrad = sums[4] / n;
+        out[7] = (((L + a0 * G) + a3 * HJt) + a4 * HJfin) + a5 * HJgrad;          // src/OCflow.py:88-90, same order
+    }
+}
+
 __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* __restrict__ b, int K, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1383,9 +1424,12 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
 
-__global__ void store_group_plan_kernel(GroupPlan gp, float* ws) {
-    if (threadIdx.x < sizeof(GroupPlan) / 4)
-        reinterpret_cast<unsigned*>(ws + gp.pp.oPlan)[threadIdx.x] = reinterpret_cast<const unsigned*>(&gp)[threadIdx.x];
+__global__ void store_group_plan_kernel(GroupPlan gp, float* ws, const float* cbp) {
+    if (threadIdx.x < sizeof(GroupPlan) / 4) {
+        unsigned v = reinterpret_cast<const unsigned*>(&gp)[threadIdx.x];
+        if (cbp && threadIdx.x == (offsetof(GroupPlan, pp) + offsetof(DevPlan, cb)) / 4) v = __float_as_uint(*cbp);
+        reinterpret_cast<unsigned*>(ws + gp.pp.oPlan)[threadIdx.x] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1500,7 +1544,7 @@ static hipError_t set_lds(KernelT kern, size_t bytes) {
 }
 
 static int pack_weights(const DevPlan& pl, const NocfPhi* phi, float* ws, hipStream_t st) {
-    DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw};
+    DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
     const long total4 = pl.oWb + (long)(pl.nTh - 1) * pl.strideW;
     int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
     if (blocks < 1) blocks = 1;
@@ -1532,6 +1576,12 @@ int nocf_debug_set_stamp_buffer(void* device_buf) {
     (void)device_buf;
     return NOCF_E_SHAPE;                                 // production build carries no stamps
 #endif
+}
+
+int nocf_cost_means_f32(const float* cost_sums, const float* alph, float* out, void* stream) {
+    if (!cost_sums || !alph || !out) return NOCF_E_NULL;
+    hipLaunchKernelGGL(cost_means_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cost_sums, alph[0], alph[3], alph[4], alph[5], out);
+    return (int)hipGetLastError();
 }
 
 int nocf_debug_set_timeline_buffer(void* device_buf) {
@@ -1627,7 +1677,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
                          pb.kind != NOCF_PROB_QUADCOPTER && pb.nAgents <= 16 && !g_stamp_buf;
     if (lane_ok) {
         LaneArgs la;
-        la.P = DevPhi{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw};
+        la.P = DevPhi{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
         la.d = phi->d; la.m = phi->m; la.r = phi->r; la.nAg = pb.nAgents; la.cb = phi->cb;
         const int grid = (int)((n + 3) / 4);
         const int MPsel = phi->m <= 16 ? 16 : 32;
@@ -1665,7 +1715,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     }
     if (use_group) {
         gp.pp.cb = phi->cb;
-        hipLaunchKernelGGL(store_group_plan_kernel, dim3(1), dim3(256), 0, st, gp, ws);
+        hipLaunchKernelGGL(store_group_plan_kernel, dim3(1), dim3(256), 0, st, gp, ws, phi->cb_dev);
         const size_t zbytes = (size_t)(gp.oX - gp.oFlags) * 4;                 // flags + error word
         e = hipMemsetAsync(ws + gp.oFlags, 0, zbytes, st);
         if (e) return (int)e;
