@@ -96,7 +96,7 @@ def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0
     :return: (Jc, cs)  or  (zFull, ctrlFull)
     """
     if (torch.is_grad_enabled() and not intermediates and not noMean
-            and any(p.requires_grad for p in Phi.parameters())):
+            and (x.requires_grad or any(p.requires_grad for p in Phi.parameters()))):
         from .train import ocflow_train                 # trainOC.py:172-173: Jc.backward() -> hand-written adjoint
         if int(nt) < 1:
             raise ValueError("nt must be >= 1")

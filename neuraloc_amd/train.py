@@ -28,6 +28,7 @@ def _step_sizes(tspan, nt):
 class _OCflowTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
+        ctx.x_needs_grad = bool(x.requires_grad)
         x = _lib.require_device_f32(x.detach(), "x")
         n, d = x.shape
         dev = x.device
@@ -79,6 +80,7 @@ class _OCflowTrain(torch.autograd.Function):
         for t in (V, Ab):
             t[:, rows - n:].zero_()
         PHIb = torch.zeros(n, device=dev)
+        lam0 = torch.empty(n, d, device=dev) if ctx.x_needs_grad else None          # dJc/dx0, like autograd's x.grad
         hs = _step_sizes(ctx.tspan, nt).to(dev)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         with torch.cuda.device(dev):
@@ -87,7 +89,7 @@ class _OCflowTrain(torch.autograd.Function):
                                                  _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs),
                                                  _lib.ptr(Y), _lib.ptr(Ob), _lib.ptr(V), _lib.ptr(Ab), _lib.ptr(Qb),
                                                  _lib.ptr(U0), _lib.ptr(Wb), _lib.ptr(Gb), _lib.ptr(Sx),
-                                                 _lib.ptr(PHIb), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                                                 _lib.ptr(PHIb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_bwd_f32")
         sT = Sx[(nt * nstage + 1) * n:]                                     # s at the final time (value rows)
         ones = torch.ones(1, rows, device=dev)                            # column sums as skinny GEMMs (HBM-bound reads)
@@ -104,7 +106,8 @@ class _OCflowTrain(torch.autograd.Function):
         if ctx.group is not None:
             from .distributed import allreduce_flat
             out = allreduce_flat(out, None if ctx.group is True else ctx.group)   # one all-reduce of all gradients
-        return (None,) * 9 + tuple(out)
+        gx = gJ * lam0 if lam0 is not None else None
+        return (gx,) + (None,) * 8 + tuple(out)
 
 
 def ocflow_train(x, net, prob, tspan, nt, stepper, alph, n_total=None, group=None):

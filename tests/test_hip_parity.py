@@ -543,3 +543,32 @@ def test_specialised_default_width_shapes_agree_with_generic(name, monkeypatch):
     assert (a[0] - b[0]).abs().max().item() <= 2e-6 * b[0].abs().max().item()
     assert abs(a[1] - b[1]) <= 2e-6 * abs(b[1])
     assert (a[2] - b[2]).abs().max().item() <= 2e-6 * b[2].abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["softcorridor", "swap12", "singlequad"])
+def test_backward_gradient_wrt_initial_states(name):
+    """x0.requires_grad: Jc.backward() also fills x0.grad (the adjoint at t0), like autograd through the reference"""
+    from conftest import load_golden
+    g = load_golden(name)
+    alph, nt = g.meta["alph"], 6
+    net = make_net(g, DEV).train()
+    prob = make_prob(g, DEV, training=True)
+    x = g.t("x")[:9].to(DEV).requires_grad_(True)
+    Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph)
+    Jc.backward()
+    P = orc.PhiParams.from_state_dict(g.state_dict(), dtype=torch.float64)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    x64 = g.t("x")[:9].double().requires_grad_(True)
+    J64, _ = orc.rollout(x64, P, S.to(torch.float64), [0.0, 1.0], nt, "rk4", alph)
+    J64.backward()
+    # the fp32 oracle (= the reference's arithmetic) differentiated by autograd gives the fp32 noise floor per sample
+    P32 = orc.PhiParams.from_state_dict(g.state_dict())
+    x32 = g.t("x")[:9].clone().requires_grad_(True)
+    J32, _ = orc.rollout(x32, P32, S, [0.0, 1.0], nt, "rk4", alph)
+    J32.backward()
+    got, want = x.grad.cpu().double(), x64.grad
+    norm = want.abs().max(dim=1).values
+    row_err = (got - want).abs().max(dim=1).values / norm
+    ref_err = (x32.grad.double() - want).abs().max(dim=1).values / norm
+    assert bool((row_err <= 4 * ref_err + 2e-4).all()), (row_err, ref_err)
