@@ -572,3 +572,53 @@ def test_backward_gradient_wrt_initial_states(name):
     row_err = (got - want).abs().max(dim=1).values / norm
     ref_err = (x32.grad.double() - want).abs().max(dim=1).values / norm
     assert bool((row_err <= 4 * ref_err + 2e-4).all()), (row_err, ref_err)
+
+
+@pytest.mark.parametrize("m,nTh,d_name", [(1024, 2, "midcross20"), (128, 6, "singlequad"), (320, 3, "swarm")])
+def test_wide_and_deep_networks_against_oracle(m, nTh, d_name):
+    """shapes far from the shipped checkpoints (16 column blocks on 8 waves; six residual layers; an odd width):
+    the generic instantiation against the oracle"""
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(5)
+    prob, x0, _, _ = na.initProb(d_name, 10, 10, 0.5, alph, lambda t: t.float().to(DEV))
+    prob.eval()
+    d = x0.shape[1]
+    sd = _synth_state_dict(nTh, m, d, seed=m % 7)
+    net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    P = orc.PhiParams.from_state_dict(sd)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    with torch.no_grad():
+        _, csn = na.OCflow(x0, net, prob, [0.0, 1.0], 5, "rk4", alph, noMean=True)
+        want = orc.persample_table(x0.cpu(), P, S, [0.0, 1.0], 5, "rk4", alph)
+    tab = torch.cat(csn, 1).cpu()
+    off = (tab.double() - want.double()).abs() > 1e-3 + 1e-3 * want.double().abs()
+    assert int(off.any(dim=1).sum()) == 0, f"{int(off.any(dim=1).sum())} samples off"
+
+
+def test_backward_on_a_time_segment_with_many_steps(golden_pretrained):
+    """tspan = [0.2, 0.7], nt = 40: the adjoint uses the same double-precision time bookkeeping as the forward sweep"""
+    g = golden_pretrained
+    alph, nt = g.meta["alph"], 40
+    net = make_net(g, DEV).train()
+    prob = make_prob(g, DEV, training=True)
+    x = g.t("x")[:6].to(DEV)
+    Jc, _ = na.OCflow(x, net, prob, [0.2, 0.7], nt, "rk4", alph)
+    Jc.backward()
+    P = orc.PhiParams.from_state_dict(g.state_dict(), dtype=torch.float64)
+    leaves = [*P.K, *P.b, P.w, P.A, P.cw, P.cb]
+    for t in leaves:
+        t.requires_grad_(True)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    J64, _ = orc.rollout(g.t("x")[:6].double(), P, S.to(torch.float64), [0.2, 0.7], nt, "rk4", alph)
+    J64.backward()
+    assert abs(Jc.item() - float(J64)) <= 2e-5 * abs(float(J64))
+    want = {"A": P.A.grad, "c.weight": P.cw.grad, "c.bias": P.cb.grad, "w.weight": P.w.grad,
+            "N.layers.0.weight": P.K[0].grad, "N.layers.0.bias": P.b[0].grad, "N.layers.1.weight": P.K[1].grad, "N.layers.1.bias": P.b[1].grad}
+    for k, p in net.named_parameters():
+        w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()
+        scale = w.abs().max().item()
+        assert (p.grad.cpu().double() - w).abs().max().item() <= 1e-3 * scale + 1e-6, k
