@@ -63,7 +63,7 @@ struct DevPlan {
     int lGB, lAB, lT0B, lQB, lOB, lSBAR, lZQB, lLAM, lXS, lXP, lXD, lSCB, lUB;   // adjoint
     int pMB, pKQc;                   // column blocks per hidden phase / k-quads of the closing phase (diagnostic: halves)
     int ldsFloats;
-    int lPW;                         // x-only cost partials formed in the shadow of the residual phases: [T][2 waves][2]
+    int lPW;                         // x-only cost partials formed in the shadow of the residual phases: [2 sets][T][2 waves][2]
 };
 
 static_assert(sizeof(DevPlan) % 4 == 0 && sizeof(DevPlan) / 4 <= 256, "plan copy is done by one 256-thread block");
@@ -160,7 +160,8 @@ constexpr int plan_layout(int d, int m, int nTh, int r, int n_agents, int bwd, i
         pl.lPHI = l; l += rup(T, 4);
         pl.lTRIG = l; l += rup(T * imax(1, n_agents) * 6, 4);
         pl.lPT = l; l += 4;                                         // (spare)
-        pl.lPW = l; l += rup(T * 4, 4);
+        pl.lPW = l; l += rup(2 * T * 4 + T * 4, 4);                 // two sets (the deferred cost side reads set e while e+1 fills
+                                                                    // the other), then sum p^2 per sample and column block [T][<=4]
         pl.nVEC = (int)(pl.oPlan - pl.ob0);
         pl.lVEC = l; l += rup(pl.nVEC, 4);
         if (bwd) {
@@ -655,11 +656,13 @@ __device__ __forceinline__ void z_from_s(const DevPlan& pl, int tid_i, int nth) 
 struct NoShadow { __device__ __forceinline__ void operator()(int) const {} };
 
 // shadow(k): extra work of the caller run by every wave at the end of the last forward residual phase (k = 0) and
-// of the first backward residual phase (k = 1), i.e. while the slower waves of those long phases still stream
+// of the first backward residual phase (k = 1), i.e. while the slower waves of those long phases still stream;
+// shadow(2) runs on the waves without a unit in the closing phase, after their share of z = A s
 template <int S, class Shadow = NoShadow>
 __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring& rg, bool& ring_ready, bool more_evals,
                          bool z_ready = false /* z = A s already sits in ZQ (the rollout's RK tail computed it) */,
-                         Shadow shadow = Shadow()) {
+                         Shadow shadow = Shadow(),
+                         bool want_p2 = false /* leave sum_i g_i^2 (i < d) per sample and column block behind the PW sets */) {
     const int T = pl.T, LD = pl.LD, m = pl.m, D1 = pl.D1, r = pl.r;
     const int oSB = pl.lSB, oTH = pl.lTH, oAV = pl.lAV, oG = pl.lG, oZQ = pl.lZQ;
     const float hN = pl.hN;
@@ -763,6 +766,7 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
     }
     TL(c, 4);
     STAMP(c, 4);
+    float p2acc[2] = {0.f, 0.f};                    // want_p2: this thread's share of sum g^2 in the two turns of the flat epilogue sweep
     // ---- closing: g = K0^T (tanh(o) . a) + A^T (A s) + c
     gemm_phase<S>(c, pl, rg, true, phClose, more_evals ? phOpen : phNone, oVs(lastLayer), LD, [&](int t, int i, float v) {
         if (i < D1) {
@@ -774,8 +778,20 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
 #pragma unroll
             for (int q = 0; q < ZQLD; ++q) g = fmaf(aq[q], zq[q], g);
             lds[oG + t * pl.GLD + i] = g;
+            if (want_p2 && i < pl.d) p2acc[(t * pl.GLD + i) >= c.nthreads ? 1 : 0] += g * g;
         }
-    }, 7, NoPost(), [&](int iw, int niw) { if (z_in_closing && !z_ready) z_from_s(pl, iw * 64 + c.lane, niw * 64); });
+    }, 7, NoPost(), [&](int iw, int niw) { if (z_in_closing && !z_ready) z_from_s(pl, iw * 64 + c.lane, niw * 64); shadow(2); });
+    if (want_p2) {
+        // the flat split-K sweep gives every wave one (sample, column block) per turn: wave totals, fixed order
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int j = c.wave * 64 + kk * c.nthreads;
+            if (j < T * pl.GLD) {
+                const float v = sum64(p2acc[kk]);
+                if (c.lane == 0) lds[pl.lPW + 2 * T * 4 + (j >> 6)] = v;
+            }
+        }
+    }
     ring_ready = more_evals;
     __syncthreads();
     TL(c, 5);
@@ -900,7 +916,7 @@ __device__ __forceinline__ float pair_sum_cyclic(const float* __restrict__ x, in
 // waves 0..3 (two per sample) at the end of residual phase k (0: forward, 1: backward) of an 8-wave, 4-sample
 // workgroup: those are the first waves of their SIMDs and finish streaming well before the second ones, so this runs
 // while the phase is still waiting for its slowest wave.  Partials go to PW[t][wave & 1][0..1].
-__device__ __forceinline__ void physics_x_shadow(const Ctx& c, const DevPlan& pl, const DevProb& pb, int k) {
+__device__ __forceinline__ void physics_x_shadow(const Ctx& c, const DevPlan& pl, const DevProb& pb, int k, int set = 0) {
     if (c.wave >= 4) return;
     const int N = pb.nAgents;
     const int t = 2 * k + (c.wave >> 1), half = c.wave & 1;
@@ -922,7 +938,7 @@ __device__ __forceinline__ void physics_x_shadow(const Ctx& c, const DevPlan& pl
         if (wantW) vw = pair_sum_cyclic<3>(x, N, j0, 128, thr, thr2, den);
     }
     vq = sum64(vq); vw = sum64(vw);
-    if (c.lane == 0) { lds[pl.lPW + t * 4 + half * 2] = vq; lds[pl.lPW + t * 4 + half * 2 + 1] = vw; }
+    if (c.lane == 0) { lds[pl.lPW + set * pl.T * 4 + t * 4 + half * 2] = vq; lds[pl.lPW + set * pl.T * 4 + t * 4 + half * 2 + 1] = vw; }
 }
 
 // Phase 1 (all threads): per-sample partial sums -> RED (ends with a barrier).
@@ -989,6 +1005,18 @@ struct Costs { float L, H, Q, W; };
 
 // Phase 2 (one thread per sample, after physics_sums): the scalars of calcLHQW.  For the quadcopter it
 // also writes -grad_p H of its sample to DZ[s][0..d) and the thrusts to SC (for calcCtrls).
+// calcLHQW of the point-agent problems from the three per-sample totals
+__device__ __forceinline__ Costs costs_point(const DevProb& pb, float sp2, float Qraw, float Wv) {
+    const bool wantW = want_W(pb);
+    Costs o;
+    float Lg;
+    if (pb.kind == NOCF_PROB_CROSS2D) { o.Q = (float)pb.alphQ * Qraw; Lg = 0.5f * sp2 + o.Q; }
+    else { o.Q = Qraw; Lg = 0.5f * sp2 + (float)pb.alphQ * Qraw; }
+    if (wantW) Lg = Lg + (float)pb.alphW * Wv;
+    o.L = Lg; o.H = -Lg + sp2; o.W = wantW ? Wv : 0.f;
+    return o;
+}
+
 __device__ Costs physics_finish(const Ctx& c, const DevPlan& pl, const DevProb& pb, int s) {
     float* Lm = lds;
     const float* X = Lm + pl.lSB;
@@ -1115,7 +1143,9 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
     Ring rg;
     bool ring_ready = false;
     bool z_next_ready = false;                      // ZQ already holds A s of the coming evaluation
-    float costZ0 = 0.f, costZA = 0.f;               // point agents: cost integrals of lane (sample, component) of the last wave
+    float costZ0 = 0.f, costZA = 0.f;               // point agents: cost integrals of lane (sample, component) of the finishing wave
+    bool pend = false; float pend_hs = 0.f; int pend_st = 0;     // deferred cost side of the previous evaluation (see below)
+    int evi = 0;                                                 // evaluation counter (parity selects the PW set)
     double tk = ra.t0;
     const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
     const int nsub = nstage + (ra.zFull ? 1 : 0);
@@ -1145,11 +1175,63 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
 #endif
             // point agents, N > 2, 8 waves x 4 samples, one residual layer: the x-only cost terms are formed in the
             // shadow of the two long phases (physics_x_shadow)
-            const bool xpre = !fin && !quad && pb.nAgents > 2 && pl.nwaves == 8 && pl.T == 4 && pl.nTh == 2;
+            const bool xshape = !quad && pb.nAgents > 2 && pl.nwaves == 8 && pl.T == 4 && pl.nTh == 2;
+            const bool xpre = !fin && xshape;
+            // ... and, without intermediates, the cost side of an evaluation (L, |dPhi/dt - H|, Q, W and their RK
+            // accumulation) is DEFERRED: nothing in it feeds the state, so evaluation e only leaves sum p^2 (from the
+            // closing epilogue), the x-only partials and dPhi/dt behind, and 16 lanes of the last wave -- which has no
+            // unit in the closing phase -- finish it during the closing phase of evaluation e+1, before that phase's
+            // epilogue overwrites grad Phi.  The state update then follows the closing barrier directly.
+            const bool deferred = xshape && pl.SK6 > 1 && pl.DB * pl.SK6 < pl.nwaves && T * pl.GLD <= 2 * c.nthreads && pl.DB <= 4 && !ra.zFull;
             phi_eval<S>(c, pl, fin, rg, ring_ready, false, z_next_ready,               // (one call site: see nocf_bwd.inc)
-                        [&](int k2) { if (xpre) physics_x_shadow(c, pl, pb, k2); });
+                        [&](int k2) {
+                            if (k2 < 2) { if (xpre) physics_x_shadow(c, pl, pb, k2, deferred ? (evi & 1) : 0); return; }
+                            if (!(deferred && pend && c.wave == pl.nwaves - 1 && c.lane < 4 * T)) return;
+                            const int s = c.lane >> 2, q = c.lane & 3;
+                            const float* P2 = lds + pl.lPW + 2 * T * 4;
+                            float sp2 = P2[s * pl.DB];
+                            for (int bk = 1; bk < pl.DB; ++bk) sp2 += P2[s * pl.DB + bk];
+                            const float* PWp = lds + pl.lPW + ((evi & 1) ^ 1) * T * 4;        // the previous evaluation's set
+                            const float Qraw = PWp[s * 4] + PWp[s * 4 + 2];
+                            const float Wv = PWp[s * 4 + 1] + PWp[s * 4 + 3];
+                            const Costs cs = costs_point(pb, sp2, Qraw, Wv);
+                            const float val = (q == 0) ? cs.L : (q == 1) ? fabsf(G[s * pl.GLD + d] - cs.H) : (q == 2) ? cs.Q : cs.W;
+                            const float K = pend_hs * val;
+                            if (nstage == 1) { costZ0 = costZ0 + K; }
+                            else if (pend_st == 0) { costZA = costZ0 + c16 * K; }
+                            else if (pend_st == 1 || pend_st == 2) { costZA += c26 * K; }
+                            else { costZ0 = costZA + c16 * K; }
+                        }, deferred && !fin);
             z_next_ready = false;
+            pend = false;
+            ++evi;
             if (fin) break;
+            if (deferred && st < nstage) {
+                // ---- state update right behind the closing barrier (src/OCflow.py:143-184, x components), straight into SB
+                double tnx;
+                if (nstage == 1) tnx = t1k;
+                else tnx = (st < 2) ? (tk + hsd / 2) : (st == 2 ? (tk + hsd) : t1k);
+                for (int j = c.tid; j < T * d; j += c.nthreads) {
+                    int t = 0, i = j;
+                    while (i >= d) { i -= d; ++t; }
+                    const float K = hs * -G[t * pl.GLD + i];
+                    const float z0 = Z0[t * ZLD + i];
+                    float xs;
+                    if (nstage == 1) { xs = z0 + K; Z0[t * ZLD + i] = xs; }
+                    else if (st == 0) { ZA[t * ZLD + i] = z0 + c16 * K; xs = z0 + 0.5f * K; }
+                    else if (st == 1) { ZA[t * ZLD + i] += c26 * K; xs = z0 + 0.5f * K; }
+                    else if (st == 2) { ZA[t * ZLD + i] += c26 * K; xs = z0 + K; }
+                    else { xs = ZA[t * ZLD + i] + c16 * K; Z0[t * ZLD + i] = xs; }
+                    SB[t * pl.LDs + i] = xs;
+                }
+                if (c.tid < T) SB[c.tid * pl.LDs + d] = (float)tnx;
+                pend = true; pend_hs = hs; pend_st = st;
+                TL(c, 43);
+                __syncthreads();
+                TL(c, 44);
+                STAMP(c, 9);
+                continue;
+            }
             // ---- RK update (src/OCflow.py:143-184): z_next accumulates, SB receives the next stage state
             const bool stage = (st < nstage);
             const bool last = (st == nstage - 1);
