@@ -374,9 +374,11 @@ struct Ctx {
     int tid, nthreads, wave, lane;
     float cb;                        // c.bias (the only plan field that is not a function of the shape)
 #ifdef NOCF_STAMPS
-    mutable unsigned long long acc[12];
+#if NOCF_STAMPS >= 2
+    mutable unsigned long long acc[12];      // per-phase cycle accumulators (24 VGPRs: they distort the kernel, level 2 only)
     mutable unsigned long long last;
-    unsigned long long* tl;          // timeline of ONE evaluation of workgroup 0: [wave][64 points] (null otherwise)
+#endif
+    unsigned long long* tl;          // timeline of ONE evaluation of one workgroup: [wave][64 points] (null otherwise)
 #endif
 };
 
@@ -386,8 +388,10 @@ __device__ __forceinline__ void ctx_init(Ctx& c, const float* ws, unsigned ws_by
     c.tid = threadIdx.x; c.nthreads = blockDim.x; c.lane = threadIdx.x & 63;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform: scalar loop control
 #ifdef NOCF_STAMPS
+#if NOCF_STAMPS >= 2
     for (int i = 0; i < 12; ++i) c.acc[i] = 0;
     c.last = clock64();
+#endif
     c.tl = nullptr;
 #endif
 }
@@ -405,7 +409,11 @@ __device__ __forceinline__ float4 wload(const Ctx& c, int voff, int soff) {
 // Diagnostic build only (-DNOCF_STAMPS): thread 0 of every workgroup accumulates the shader cycles
 // each phase takes (barrier waits included).  The production library contains no stamp.
 #ifdef NOCF_STAMPS
+#if NOCF_STAMPS >= 2
 #define STAMP(c, id) do { if ((c).tid == 0) { unsigned long long t_ = clock64(); (c).acc[id] += t_ - (c).last; (c).last = t_; } } while (0)
+#else
+#define STAMP(c, id) do { } while (0)
+#endif
 #define TL(c, id) do { if ((c).tl && (c).lane == 0) (c).tl[(c).wave * 64 + (id)] = clock64(); } while (0)
 __device__ unsigned long long* g_tl_dev = nullptr;       // timeline buffer of the adjoint kernel (set with the stamp buffer)
 #else
@@ -1346,7 +1354,7 @@ __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* _
         }
         tk += ra.h;
     }
-#ifdef NOCF_STAMPS
+#if defined(NOCF_STAMPS) && NOCF_STAMPS >= 2
     if (ra.stamps && c.tid == 0)
         for (int i = 0; i < 12; ++i) ra.stamps[(long)blockIdx.x * 12 + i] = c.acc[i];
 #endif

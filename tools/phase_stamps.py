@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase shader-cycle shares of the rollout kernel, from the -DNOCF_STAMPS build.
 
-  hipcc ... -DNOCF_STAMPS -o neuraloc_amd/csrc/libnocf_stamps.so   (tools/build_stamps.sh)
+  NOCF_STAMPS_LEVEL=2 tools/build_stamps.sh   (hipcc ... -DNOCF_STAMPS=2 -o neuraloc_amd/csrc/libnocf_stamps.so)
   NOCF_LIB_PATH=neuraloc_amd/csrc/libnocf_stamps.so python tools/phase_stamps.py [workload]
 
 Read the SHARES, not the absolute time: the stamps add fences the production kernel does not have.
