@@ -166,6 +166,16 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
                          float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
                          float* PHIb, float* lam0, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * C[m, n] (+)= sum_k A[k, 0..m) (x) B[k, 0..n) for small m, n (<= 64) and very many rows: the contraction of the rows that
+ * nocf_rollout_bwd_f32 streams into the weight gradients of a SMALL network (what torch autograd does with one mm per
+ * parameter in the backward of trainOC.py:173).  Two launches, deterministic.  Wider networks contract with library GEMMs.
+ *   A device [K, m], B device [K, n] row-major;  C device [m, n];  accumulate != 0 adds to C
+ *   scratch device [scratch_floats]: >= 4096 floats per workgroup used (up to 1024 workgroups, one per >= 256 rows)
+ */
+int nocf_contract_f32(const float* A, const float* B, int64_t K, int32_t m, int32_t n, float* C, int32_t accumulate,
+                      float* scratch, size_t scratch_floats, void* stream);
+
 /* Phi.getGrad -- replaces src/Phi.py:99-138.  s: device [n, d+1] -> grad: device [n, d+1] */
 int nocf_phi_grad_f32(const NocfPhi* phi, const float* s, int64_t n, float* grad,
                       void* workspace, size_t workspace_bytes, void* stream);

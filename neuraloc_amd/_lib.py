@@ -57,6 +57,9 @@ def lib():
                                    C.c_double, C.c_double, C.c_int32, C.c_int32, fp,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]
+    L.nocf_contract_f32.restype = C.c_int
+    L.nocf_contract_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]
     L.nocf_cost_means_f32.restype = C.c_int
     L.nocf_cost_means_f32.argtypes = [C.c_void_p, fp, C.c_void_p, C.c_void_p]
     L.nocf_rollout_record_f32.restype = C.c_int

@@ -1503,6 +1503,70 @@ __global__ void cost_means_kernel(const float* __restrict__ sums, float a0, floa
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// C[m x n] (+)= sum_k A[k][0..m) (x) B[k][0..n) for SMALL m, n (<= 64) and very many rows k: the weight-gradient
+// contractions of the small networks (rows = samples x evaluations, 10^5..10^6).  A library GEMM with a 32x32 output
+// runs on one workgroup there (0.4 ms each); this is HBM-bound work (read both row streams once).
+// Stage 1: every workgroup owns a slice of the rows, stages 32 rows at a time in LDS, 16x16 threads keep a 4x4 tile
+// of C in registers; stage 2 adds the per-workgroup partials in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------
+#define CT_ROWS 32
+__global__ void __launch_bounds__(256) contract_partial_kernel(const float* __restrict__ A, const float* __restrict__ B, long K, int m, int n,
+                                                               long rows_per_block, float* __restrict__ part) {
+    __shared__ float sA[CT_ROWS][64 + 4], sB[CT_ROWS][64 + 4];
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int rr0 = tid >> 6, cc = tid & 63;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = (r0 + rows_per_block < K) ? r0 + rows_per_block : K;
+    for (long r = r0; r < r1; r += CT_ROWS) {
+#pragma unroll
+        for (int p = 0; p < CT_ROWS / 4; ++p) {
+            const int rr = p * 4 + rr0;
+            const long row = r + rr;
+            sA[rr][cc] = (row < r1 && cc < m) ? A[row * m + cc] : 0.f;
+            sB[rr][cc] = (row < r1 && cc < n) ? B[row * n + cc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < CT_ROWS; ++rr) {
+            const float4 a = *reinterpret_cast<const float4*>(&sA[rr][4 * ti]);
+            const float4 b = *reinterpret_cast<const float4*>(&sB[rr][4 * tj]);
+            acc[0][0] = fmaf(a.x, b.x, acc[0][0]); acc[0][1] = fmaf(a.x, b.y, acc[0][1]); acc[0][2] = fmaf(a.x, b.z, acc[0][2]); acc[0][3] = fmaf(a.x, b.w, acc[0][3]);
+            acc[1][0] = fmaf(a.y, b.x, acc[1][0]); acc[1][1] = fmaf(a.y, b.y, acc[1][1]); acc[1][2] = fmaf(a.y, b.z, acc[1][2]); acc[1][3] = fmaf(a.y, b.w, acc[1][3]);
+            acc[2][0] = fmaf(a.z, b.x, acc[2][0]); acc[2][1] = fmaf(a.z, b.y, acc[2][1]); acc[2][2] = fmaf(a.z, b.z, acc[2][2]); acc[2][3] = fmaf(a.z, b.w, acc[2][3]);
+            acc[3][0] = fmaf(a.w, b.x, acc[3][0]); acc[3][1] = fmaf(a.w, b.y, acc[3][1]); acc[3][2] = fmaf(a.w, b.z, acc[3][2]); acc[3][3] = fmaf(a.w, b.w, acc[3][3]);
+        }
+        __syncthreads();
+    }
+    float* o = part + (long)blockIdx.x * 4096;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        *reinterpret_cast<float4*>(&o[(4 * ti + a) * 64 + 4 * tj]) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+}
+
+// stage 2: 16 outputs per workgroup, 16 threads per output each summing every 16th partial, then a fixed-order LDS sum
+__global__ void __launch_bounds__(256) contract_reduce_kernel(const float* __restrict__ part, int nblocks, int m, int n, float* __restrict__ C, int accumulate) {
+    __shared__ float sh[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + o;
+    float s = 0.f;
+    for (int b = sl; b < nblocks; b += 16) s += part[(long)b * 4096 + idx];
+    sh[sl][o] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t = sh[0][o];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += sh[q][o];
+        const int i = idx >> 6, j = idx & 63;
+        if (i < m && j < n) C[i * n + j] = accumulate ? C[i * n + j] + t : t;
+    }
+}
+
 __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* __restrict__ b, int K, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1671,6 +1735,23 @@ int nocf_debug_set_stamp_buffer(void* device_buf) {
 int nocf_cost_means_f32(const float* cost_sums, const float* alph, float* out, void* stream) {
     if (!cost_sums || !alph || !out) return NOCF_E_NULL;
     hipLaunchKernelGGL(cost_means_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cost_sums, alph[0], alph[3], alph[4], alph[5], out);
+    return (int)hipGetLastError();
+}
+
+int nocf_contract_f32(const float* A, const float* B, int64_t K, int32_t m, int32_t n, float* C, int32_t accumulate,
+                      float* scratch, size_t scratch_floats, void* stream) {
+    if (!A || !B || !C || !scratch) return NOCF_E_NULL;
+    if (K < 1 || m < 1 || n < 1 || m > 64 || n > 64) return NOCF_E_SHAPE;
+    long nblocks = (K + 255) / 256;                       // >= 256 rows per workgroup
+    if (nblocks > 1024) nblocks = 1024;
+    if ((size_t)nblocks * 4096 > scratch_floats) nblocks = (long)(scratch_floats / 4096);
+    if (nblocks < 1) return NOCF_E_WORKSPACE;
+    long rpb = (K + nblocks - 1) / nblocks;
+    rpb = (rpb + CT_ROWS - 1) / CT_ROWS * CT_ROWS;
+    nblocks = (K + rpb - 1) / rpb;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(contract_partial_kernel, dim3((int)nblocks), dim3(256), 0, st, A, B, (long)K, m, n, rpb, scratch);
+    hipLaunchKernelGGL(contract_reduce_kernel, dim3((m * 64 + 15) / 16), dim3(256), 0, st, scratch, (int)nblocks, m, n, C, accumulate);
     return (int)hipGetLastError();
 }
 

@@ -25,6 +25,31 @@ def _step_sizes(tspan, nt):
     return torch.tensor(out, dtype=torch.float32)
 
 
+_SCRATCH = {}
+
+
+def _contract(X, Y, out=None):
+    """X' Y for row streams X [K, m], Y [K, n] (out += when given).  Small outputs (m, n <= 64: the 2-12 agent
+    networks) go to the library's two-launch contraction (a library GEMM with a 32x32 output runs on one workgroup:
+    0.4 ms each); wide ones are library GEMMs (hipBLASLt, near its fp32 peak for 512x512 outputs)."""
+    m, n = X.shape[1], Y.shape[1]
+    if m > 64 or n > 64:
+        r = X.t() @ Y
+        return r if out is None else out.add_(r)
+    dev = X.device
+    sc = _SCRATCH.get(dev)
+    if sc is None:
+        sc = _SCRATCH[dev] = torch.empty(1024 * 4096, device=dev)
+    acc = out is not None
+    if out is None:
+        out = torch.empty(m, n, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().nocf_contract_f32(_lib.ptr(X), _lib.ptr(Y), X.shape[0], m, n, _lib.ptr(out), int(acc),
+                                          _lib.ptr(sc), sc.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "nocf_contract_f32")
+    return out
+
+
 class _OCflowTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
@@ -92,15 +117,15 @@ class _OCflowTrain(torch.autograd.Function):
                                                  _lib.ptr(PHIb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_bwd_f32")
         sT = Sx[(nt * nstage + 1) * n:]                                     # s at the final time (value rows)
-        ones = torch.ones(1, rows, device=dev)                            # column sums as skinny GEMMs (HBM-bound reads)
-        grads = {"N.layers.0.weight": Y.t() @ Gb + Ob.t() @ Sx, "N.layers.0.bias": (ones @ Ob).reshape(-1)}
+        ones = torch.ones(rows, 1, device=dev)                            # column sums are contractions with a column of ones
+        grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": _contract(ones, Ob).reshape(-1)}
         for i in range(1, L + 1):
-            grads[f"N.layers.{i}.weight"] = V[i - 1].t() @ Ab[i - 1] + Qb[i - 1].t() @ U0[i - 1]
-            grads[f"N.layers.{i}.bias"] = (ones @ Qb[i - 1]).reshape(-1)
-        grads["w.weight"] = ones @ Wb
-        grads["c.weight"] = ((ones @ Gb).reshape(-1) + PHIb @ sT).reshape(1, -1)
+            grads[f"N.layers.{i}.weight"] = _contract(Qb[i - 1], U0[i - 1], _contract(V[i - 1], Ab[i - 1]))
+            grads[f"N.layers.{i}.bias"] = _contract(ones, Qb[i - 1]).reshape(-1)
+        grads["w.weight"] = _contract(ones, Wb)
+        grads["c.weight"] = (_contract(ones, Gb).reshape(-1) + PHIb @ sT).reshape(1, -1)
         grads["c.bias"] = PHIb.sum().reshape(1)
-        dM = Gb.t() @ Sx + 0.5 * (sT * PHIb[:, None]).t() @ sT
+        dM = _contract(Gb, Sx) + 0.5 * (sT * PHIb[:, None]).t() @ sT
         grads["A"] = net.A.detach() @ (dM + dM.t())
         out = [gJ * grads[name] for name, _ in net.named_parameters()]
         if ctx.group is not None:

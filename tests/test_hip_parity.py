@@ -622,3 +622,20 @@ def test_backward_on_a_time_segment_with_many_steps(golden_pretrained):
         w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()
         scale = w.abs().max().item()
         assert (p.grad.cpu().double() - w).abs().max().item() <= 1e-3 * scale + 1e-6, k
+
+
+@pytest.mark.parametrize("K,m,n", [(1, 1, 1), (257, 32, 25), (5000, 16, 5), (40001, 64, 64), (1000, 1, 33), (333, 61, 3)])
+def test_small_output_contraction_kernel(K, m, n):
+    """nocf_contract_f32 (the weight-gradient contraction of the small networks) against a float64 matmul; accumulate mode"""
+    from neuraloc_amd.train import _contract
+    g = torch.Generator().manual_seed(K + m + n)
+    X = torch.randn(K, m, generator=g).to(DEV)
+    Y = torch.randn(K, n, generator=g).to(DEV)
+    want = (X.double().t() @ Y.double()).cpu()
+    got = _contract(X, Y).cpu().double()
+    tol = 1e-5 * (K ** 0.5) + 1e-5
+    assert got.shape == want.shape and (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    acc = _contract(X, Y, _contract(X, Y)).cpu().double()
+    assert (acc - 2 * want).abs().max().item() <= 2 * tol * max(1.0, want.abs().max().item())
+    again = _contract(X, Y).cpu().double()
+    assert torch.equal(again, got)                       # fixed-order two-stage sum: run-to-run identical
