@@ -1844,7 +1844,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const unsigned* errp = nullptr;
     // small networks: one wave per sample, everything in registers (nocf_lane.inc); needs no packed images
-    const bool lane_ok = !s_all && env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&
+    const bool lane_ok = env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&
                          pb.kind != NOCF_PROB_QUADCOPTER && pb.nAgents <= 16 && !g_stamp_buf;
     if (lane_ok) {
         LaneArgs la;
