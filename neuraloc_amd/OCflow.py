@@ -53,7 +53,8 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
         ctrlFull = torch.empty(nt + 1, n, cdim, dtype=torch.float32, device=dev)
     alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
     with torch.cuda.device(dev):
-        rc = _lib.lib().nocf_rollout_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+        L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents)
+        rc = L.nocf_rollout_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
                                          float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
                                          None, _lib.ptr(persample), _lib.ptr(sums),
                                          _lib.ptr(zFull), _lib.ptr(ctrlFull),

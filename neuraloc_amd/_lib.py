@@ -44,7 +44,50 @@ def lib():
         raise RuntimeError(f"neuraloc_amd: HIP library {LIB_PATH} is missing. Build it with "
                            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                            "There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+# shapes (d, m, nTh, r, agents) the shipped library already specialises (FIXED_SHAPES / FIXED_SHAPES_TRAIN in nocf_kernels.hip)
+_BUILTIN_SHAPES = {(150, 512, 2, 10, 50), (12, 128, 2, 10, 1), (40, 32, 2, 10, 20), (60, 32, 2, 10, 30), (96, 32, 2, 10, 32),
+                   (4, 16, 2, 5, 2), (4, 32, 2, 5, 2), (24, 32, 2, 10, 12), (8, 32, 2, 9, 4), (12, 32, 2, 10, 6),
+                   (16, 32, 2, 10, 8), (20, 32, 2, 10, 10)}
+_jit_libs = {}
+
+
+def lib_for(d, m, nTh, r, n_agents):
+    """The library to run a rollout of this shape with.  Normally the shipped one (its generic kernel instantiation takes
+    any shape).  With NOCF_JIT=1 a shape it does not specialise gets its own library: the same source compiled by hipcc
+    with -DNOCF_XS_* (the plan as a compile-time constant: 1.3-1.8x on the tile kernels), once, cached under
+    csrc/jit/.  Same C ABI, same entry points."""
+    key = (int(d), int(m), int(nTh), int(r), int(n_agents))
+    if os.environ.get("NOCF_JIT", "0") in ("", "0") or key in _BUILTIN_SHAPES or "NOCF_LIB_PATH" in os.environ:
+        return lib()
+    L = _jit_libs.get(key)
+    if L is not None:
+        return L
+    import subprocess
+    import sys
+    csrc = os.path.dirname(os.path.abspath(LIB_PATH))
+    out_dir = os.path.join(csrc, "jit")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libnocf_d%d_m%d_t%d_r%d_a%d.so" % key)
+    src = os.path.join(csrc, "nocf_kernels.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        inc = os.path.join(os.path.dirname(os.path.dirname(csrc)), "include")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNOCF_JIT_ONLY",
+               "-DNOCF_XS_D=%d" % key[0], "-DNOCF_XS_M=%d" % key[1], "-DNOCF_XS_T=%d" % key[2], "-DNOCF_XS_R=%d" % key[3],
+               "-DNOCF_XS_A=%d" % key[4], "-I" + inc, "-I" + csrc, "-o", so + ".tmp", src]
+        print("[neuraloc_amd] NOCF_JIT=1: specialising the kernels for shape d=%d m=%d nTh=%d r=%d agents=%d (about a minute, once)" % key,
+              file=sys.stderr, flush=True)
+        subprocess.check_call(cmd)
+        os.replace(so + ".tmp", so)
+    L = _jit_libs[key] = _bind(C.CDLL(so))
+    return L
+
+
+def _bind(L):
     L.nocf_version.restype = C.c_int
     L.nocf_workspace_bytes.restype = C.c_size_t
     L.nocf_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
@@ -85,7 +128,6 @@ def lib():
     L.nocf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     L.nocf_selftest_mfma.restype = C.c_int
     L.nocf_selftest_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
-    _lib = L
     return L
 
 

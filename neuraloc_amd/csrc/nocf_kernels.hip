@@ -199,11 +199,24 @@ struct FixedPlan {
 // shapes with a specialised instantiation: (d, m, nTh, r, agents).  First the BASELINE.json tile-kernel configurations
 // (swarm50, singlequad), then the initProb problems whose d+1 exceeds the lane kernel's 32 at the reference's default
 // width m = 32 (midcross20, midcross30, swarm).
+// A build with -DNOCF_XS_D=d -DNOCF_XS_M=m -DNOCF_XS_T=nTh -DNOCF_XS_R=r -DNOCF_XS_A=agents adds one more (evaluation,
+// record and adjoint); with -DNOCF_JIT_ONLY it carries only that one: neuraloc_amd/_lib.py builds such a library per
+// shape on request (NOCF_JIT=1).
+#ifdef NOCF_XS_D
+#define FIXED_SHAPES_EXTRA(X) X(NOCF_XS_D, NOCF_XS_M, NOCF_XS_T, NOCF_XS_R, NOCF_XS_A)
+#else
+#define FIXED_SHAPES_EXTRA(X)
+#endif
+#ifdef NOCF_JIT_ONLY
+#define FIXED_SHAPES(X)
+#define FIXED_SHAPES_TRAIN(X)
+#else
 #define FIXED_SHAPES(X) X(150, 512, 2, 10, 50) X(12, 128, 2, 10, 1) X(40, 32, 2, 10, 20) X(60, 32, 2, 10, 30) X(96, 32, 2, 10, 32)
 // small shapes: evaluation takes the lane kernel, TRAINING (record + adjoint) takes the tile kernels -- the other
 // BASELINE configs (swap2, softcorridor = midcross2 = swap12_1pair, swap12) and the remaining initProb problems at m = 32
 #define FIXED_SHAPES_TRAIN(X) X(4, 16, 2, 5, 2) X(4, 32, 2, 5, 2) X(24, 32, 2, 10, 12) \
     X(8, 32, 2, 9, 4) X(12, 32, 2, 10, 6) X(16, 32, 2, 10, 8) X(20, 32, 2, 10, 10)
+#endif
 
 template <class SP>
 static bool plan_is(const DevPlan& run) {
@@ -1921,6 +1934,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
 #define NOCF_TRY_FIXED(D, M, NTH, R, NAG) \
             if (!fk && plan_is<FixedPlan<D, M, NTH, R, NAG, 0>>(pl)) fk = reinterpret_cast<const void*>(rollout_kernel<1, FixedPlan<D, M, NTH, R, NAG, 0>>);
             FIXED_SHAPES(NOCF_TRY_FIXED)
+            FIXED_SHAPES_EXTRA(NOCF_TRY_FIXED)
             if (s_all) { FIXED_SHAPES_TRAIN(NOCF_TRY_FIXED) }
 #undef NOCF_TRY_FIXED
             if (fk) {
@@ -2005,6 +2019,7 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
 #define NOCF_TRY_FIXED(D, M, NTH, R, NAG) \
         if (!fk && plan_is<FixedPlan<D, M, NTH, R, NAG, 1>>(pl)) fk = reinterpret_cast<const void*>(rollout_bwd_kernel<1, FixedPlan<D, M, NTH, R, NAG, 1>>);
         FIXED_SHAPES(NOCF_TRY_FIXED)
+        FIXED_SHAPES_EXTRA(NOCF_TRY_FIXED)
         FIXED_SHAPES_TRAIN(NOCF_TRY_FIXED)
 #undef NOCF_TRY_FIXED
     }

@@ -66,7 +66,8 @@ class _OCflowTrain(torch.autograd.Function):
         s_all = torch.empty(nt * nstage, n, d + 1, device=dev)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         with torch.cuda.device(dev):
-            rc = _lib.lib().nocf_rollout_record_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+            rc = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents).nocf_rollout_record_f32(
+                                                    C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
                                                     float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
                                                     _lib.ptr(z_out), _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(s_all),
                                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
@@ -109,7 +110,8 @@ class _OCflowTrain(torch.autograd.Function):
         hs = _step_sizes(ctx.tspan, nt).to(dev)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         with torch.cuda.device(dev):
-            rc = _lib.lib().nocf_rollout_bwd_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
+            rc = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents).nocf_rollout_bwd_f32(
+                                                 C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
                                                  float(ctx.tspan[1]), alph_c, 1.0 / float(ctx.n_total),
                                                  _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs),
                                                  _lib.ptr(Y), _lib.ptr(Ob), _lib.ptr(V), _lib.ptr(Ab), _lib.ptr(Qb),

@@ -643,3 +643,37 @@ def test_small_output_contraction_kernel(K, m, n):
     assert (acc - 2 * want).abs().max().item() <= 2 * tol * max(1.0, want.abs().max().item())
     again = _contract(X, Y).cpu().double()
     assert torch.equal(again, got)                       # fixed-order two-stage sum: run-to-run identical
+
+
+def test_jit_specialisation_of_an_unlisted_shape(monkeypatch, capfd):
+    """NOCF_JIT=1: a shape without a built-in specialised instantiation gets its own library (hipcc, once, cached);
+    it takes the specialised kernels and agrees with the generic instantiation"""
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this box")
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(9)
+    prob, x0, _, _ = na.initProb("midcross4", 16, 16, 0.5, alph, lambda t: t.float().to(DEV))
+    d, m = x0.shape[1], 48
+    sd = _synth_state_dict(2, m, d, seed=4)
+    out = {}
+    for jit in ("0", "1"):
+        monkeypatch.setenv("NOCF_JIT", jit)
+        monkeypatch.setenv("NOCF_DEBUG", "1")
+        net = na.Phi(nTh=2, m=m, d=d, alph=alph)
+        net.load_state_dict(sd)
+        net = net.to(DEV)
+        prob.eval()
+        capfd.readouterr()
+        with torch.no_grad():
+            _, csn = na.OCflow(x0, net, prob, [0.0, 1.0], 6, "rk4", alph, noMean=True)
+        err = capfd.readouterr().err
+        assert ("shape-specialised" in err) == (jit == "1"), err[-400:]
+        net.train(); prob.train()
+        Jc, _ = na.OCflow(x0, net, prob, [0.0, 1.0], 6, "rk4", alph)
+        Jc.backward()
+        out[jit] = (torch.cat(csn, 1).cpu(), Jc.item(), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu())
+    a, b = out["1"], out["0"]
+    assert (a[0] - b[0]).abs().max().item() <= 2e-6 * b[0].abs().max().item()
+    assert abs(a[1] - b[1]) <= 2e-6 * abs(b[1])
+    assert (a[2] - b[2]).abs().max().item() <= 2e-6 * b[2].abs().max().item()
