@@ -21,33 +21,41 @@ from neuraloc_amd.checkpoint import save_checkpoint
 from neuraloc_amd.initProb import PROBLEM_NAMES, initProb, resample
 
 
+# (flag, type, default, note) -- names and defaults are the reference driver's (trainOC.py:22-63); notes are ours
+_FLAGS = [
+    ("data", str, "softcorridor", "problem name"),
+    ("nt", int, 20, "RK4 steps while training"),
+    ("nt_val", int, 32, "RK4 steps in validation plots (kept for compatibility)"),
+    ("alph", str, "100.0, 10000.0, 300.0, 0.2, 0.2, 0.2", "weights of G, Q, W, HJt, HJfin, HJgrad"),
+    ("m", int, 32, "width of Phi"),
+    ("nTh", int, 2, "depth of Phi"),
+    ("niters", int, 1800, "Adam iterations"),
+    ("lr", float, 0.01, "learning rate"),
+    ("optim", str, "adam", "only adam"),
+    ("weight_decay", float, 0.0, ""),
+    ("resume", str, None, "checkpoint to continue from"),
+    ("save", str, "experiments/oc/run", "output directory"),
+    ("gpu", int, 0, "device index of a single-process run"),
+    ("prec", str, "single", "the HIP path is fp32"),
+    ("approach", str, "ocflow", ""),
+    ("viz_freq", int, 100, "ignored: nothing is plotted"),
+    ("val_freq", int, 25, "validate every this many iterations"),
+    ("log_freq", int, 1, "print every this many iterations"),
+    ("lr_freq", int, 600, "decay the learning rate every this many iterations"),
+    ("lr_decay", float, 0.1, "decay factor"),
+    ("n_train", int, 1024, "GLOBAL batch size"),
+    ("var0", float, 1.0, "scale of rho_0"),
+    ("sample_freq", int, 100, "draw a new batch every this many iterations"),
+    ("new_alph", str, None, "'iter, a0, ..., a5': switch the weights at that iteration"),
+    ("seed", int, None, "torch seed (rank is added); the reference is unseeded"),
+]
+_CHOICES = {"data": PROBLEM_NAMES, "optim": ["adam"], "prec": ["single"], "approach": ["ocflow"]}
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser("Optimal Control (MI355X)")
-    p.add_argument("--data", choices=PROBLEM_NAMES, type=str, default="softcorridor")
-    p.add_argument("--nt", type=int, default=20, help="number of time steps")
-    p.add_argument("--nt_val", type=int, default=32, help="number of time steps for validation")
-    p.add_argument("--alph", type=str, default="100.0, 10000.0, 300.0, 0.2, 0.2, 0.2")   # G, Q, W, HJt, HJfin, HJgrad
-    p.add_argument("--m", type=int, default=32, help="NN width")
-    p.add_argument("--nTh", type=int, default=2, help="NN depth")
-    p.add_argument("--niters", type=int, default=1800)
-    p.add_argument("--lr", type=float, default=0.01)
-    p.add_argument("--optim", type=str, default="adam", choices=["adam"])
-    p.add_argument("--weight_decay", type=float, default=0.0)
-    p.add_argument("--resume", type=str, default=None, help="for loading a pretrained model")
-    p.add_argument("--save", type=str, default="experiments/oc/run", help="define the save directory")
-    p.add_argument("--gpu", type=int, default=0, help="send to specific gpu (single-process runs)")
-    p.add_argument("--prec", type=str, default="single", choices=["single"], help="the HIP path is fp32")
-    p.add_argument("--approach", type=str, default="ocflow", choices=["ocflow"])
-    p.add_argument("--viz_freq", type=int, default=100, help="accepted for compatibility; nothing is plotted")
-    p.add_argument("--val_freq", type=int, default=25, help="how often to run model on validation set")
-    p.add_argument("--log_freq", type=int, default=1, help="how often to print results to log")
-    p.add_argument("--lr_freq", type=int, default=600, help="how often to decrease lr")
-    p.add_argument("--lr_decay", type=float, default=0.1, help="how much to decrease lr")
-    p.add_argument("--n_train", type=int, default=1024, help="number of training samples (global)")
-    p.add_argument("--var0", type=float, default=1.0, help="variance of rho_0 to sample from")
-    p.add_argument("--sample_freq", type=int, default=100, help="how often to resample training data")
-    p.add_argument("--new_alph", type=str, default=None, help="'iter, a0, ..., a5': switch alph weights at that iteration")
-    p.add_argument("--seed", type=int, default=None, help="torch seed (rank is added); the reference is unseeded")
+    for name, typ, dflt, note in _FLAGS:
+        p.add_argument("--" + name, type=typ, default=dflt, help=note or None, choices=_CHOICES.get(name))
     a = p.parse_args(argv)
     a.alph = [float(v) for v in a.alph.split(",")]
     if a.new_alph is not None:
