@@ -6,7 +6,7 @@ evalOC.py:113-122, softcorridor only there): nShock = int(t_s*nt) steps on [t0, 
 shocks at once (the BASELINE "singlequad shock-eval sweep"); both segments are the fused HIP rollout."""
 import torch
 
-from .OCflow import OCflow
+from .OCflow import _launch, costs_from_sums
 
 
 def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, stepper="rk4"):
@@ -28,12 +28,16 @@ def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, ste
         # the reference would divide by zero (nShock = 0) or integrate backwards; SURVEY 8a note 10
         raise ValueError(f"shock time {t_s} gives nShock={nShock}; need 1 <= int(t_s*nt) <= nt")
     shock = torch.as_tensor(shock, dtype=x.dtype, device=x.device)
-    z1, c1 = OCflow(x, Phi, prob, [tspan[0], t_s], nShock, stepper, alph, intermediates=True)
-    costs1 = OCflow(x, Phi, prob, [tspan[0], t_s], nShock, stepper, alph)
-    xs = (z1[:, :d, -1] + shock).contiguous()
-    n2 = 1 + nt - nShock
-    z2, c2 = OCflow(xs, Phi, prob, [t_s, tspan[1]], n2, stepper, alph, intermediates=True)
-    costs2 = OCflow(xs, Phi, prob, [t_s, tspan[1]], n2, stepper, alph)
+    # one launch per segment gives the trajectory, the controls AND the cost sums (the reference runs OCflow twice)
+    with torch.no_grad():
+        _, sums1, zF1, cF1 = _launch(x, Phi, prob, [tspan[0], t_s], nShock, stepper, alph, True)
+        z1, c1 = zF1.permute(1, 2, 0), cF1.permute(1, 2, 0)
+        costs1 = costs_from_sums(sums1, alph)
+        xs = (z1[:, :d, -1] + shock).contiguous()
+        n2 = 1 + nt - nShock
+        _, sums2, zF2, cF2 = _launch(xs, Phi, prob, [t_s, tspan[1]], n2, stepper, alph, True)
+        z2, c2 = zF2.permute(1, 2, 0), cF2.permute(1, 2, 0)
+        costs2 = costs_from_sums(sums2, alph)
     return {"traj": torch.cat((z1[:, :d, :], z2[:, :d, :]), dim=2), "ctrl": torch.cat((c1, c2), dim=2),
             "costs1": costs1, "costs2": costs2, "nShock": nShock, "x_shocked": xs}
 
