@@ -167,11 +167,12 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
                          float* PHIb, float* lam0, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * C[m, n] (+)= sum_k A[k, 0..m) (x) B[k, 0..n) for small m, n (<= 64) and very many rows: the contraction of the rows that
+ * C[m, n] (+)= sum_k A[k, 0..m) (x) B[k, 0..n) for small outputs (m, n <= 512, at most 64 tiles of 64 x 64) and very many rows: the contraction of the rows that
  * nocf_rollout_bwd_f32 streams into the weight gradients of a SMALL network (what torch autograd does with one mm per
  * parameter in the backward of trainOC.py:173).  Two launches, deterministic.  Wider networks contract with library GEMMs.
  *   A device [K, m], B device [K, n] row-major;  C device [m, n];  accumulate != 0 adds to C
- *   scratch device [scratch_floats]: >= 4096 floats per workgroup used (up to 1024 workgroups, one per >= 256 rows)
+ *   scratch device [scratch_floats]: 4096 floats per workgroup and 64x64 output tile (up to 1024 of them, one workgroup per
+ *           >= 256 rows and tile)
  */
 int nocf_contract_f32(const float* A, const float* B, int64_t K, int32_t m, int32_t n, float* C, int32_t accumulate,
                       float* scratch, size_t scratch_floats, void* stream);

@@ -1524,11 +1524,13 @@ __global__ void cost_means_kernel(const float* __restrict__ sums, float a0, floa
 // of C in registers; stage 2 adds the per-workgroup partials in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------
 #define CT_ROWS 32
+// grid (row slices, 64x64 output tiles); tile (ti0, tj0) of C = columns [64 ti0, +64) of A against [64 tj0, +64) of B
 __global__ void __launch_bounds__(256) contract_partial_kernel(const float* __restrict__ A, const float* __restrict__ B, long K, int m, int n,
-                                                               long rows_per_block, float* __restrict__ part) {
+                                                               long rows_per_block, int tiles_j, float* __restrict__ part) {
     __shared__ float sA[CT_ROWS][64 + 4], sB[CT_ROWS][64 + 4];
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const int rr0 = tid >> 6, cc = tid & 63;
+    const int tile = blockIdx.y, i0 = (tile / tiles_j) * 64, j0 = (tile % tiles_j) * 64;
     float acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -1541,8 +1543,8 @@ __global__ void __launch_bounds__(256) contract_partial_kernel(const float* __re
         for (int p = 0; p < CT_ROWS / 4; ++p) {
             const int rr = p * 4 + rr0;
             const long row = r + rr;
-            sA[rr][cc] = (row < r1 && cc < m) ? A[row * m + cc] : 0.f;
-            sB[rr][cc] = (row < r1 && cc < n) ? B[row * n + cc] : 0.f;
+            sA[rr][cc] = (row < r1 && i0 + cc < m) ? A[row * m + i0 + cc] : 0.f;
+            sB[rr][cc] = (row < r1 && j0 + cc < n) ? B[row * n + j0 + cc] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -1556,27 +1558,29 @@ __global__ void __launch_bounds__(256) contract_partial_kernel(const float* __re
         }
         __syncthreads();
     }
-    float* o = part + (long)blockIdx.x * 4096;
+    float* o = part + ((long)blockIdx.x * gridDim.y + tile) * 4096;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
         *reinterpret_cast<float4*>(&o[(4 * ti + a) * 64 + 4 * tj]) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
 }
 
 // stage 2: 16 outputs per workgroup, 16 threads per output each summing every 16th partial, then a fixed-order LDS sum
-__global__ void __launch_bounds__(256) contract_reduce_kernel(const float* __restrict__ part, int nblocks, int m, int n, float* __restrict__ C, int accumulate) {
+__global__ void __launch_bounds__(256) contract_reduce_kernel(const float* __restrict__ part, int nblocks, int m, int n, int tiles_j,
+                                                              float* __restrict__ C, int accumulate) {
     __shared__ float sh[16][17];
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + o;
+    const int tile = blockIdx.y, ntiles = gridDim.y;
     float s = 0.f;
-    for (int b = sl; b < nblocks; b += 16) s += part[(long)b * 4096 + idx];
+    for (int b = sl; b < nblocks; b += 16) s += part[((long)b * ntiles + tile) * 4096 + idx];
     sh[sl][o] = s;
     __syncthreads();
     if (sl == 0) {
         float t = sh[0][o];
 #pragma unroll
         for (int q = 1; q < 16; ++q) t += sh[q][o];
-        const int i = idx >> 6, j = idx & 63;
-        if (i < m && j < n) C[i * n + j] = accumulate ? C[i * n + j] + t : t;
+        const int i = (tile / tiles_j) * 64 + (idx >> 6), j = (tile % tiles_j) * 64 + (idx & 63);
+        if (i < m && j < n) C[(long)i * n + j] = accumulate ? C[(long)i * n + j] + t : t;
     }
 }
 
@@ -1754,17 +1758,19 @@ int nocf_cost_means_f32(const float* cost_sums, const float* alph, float* out, v
 int nocf_contract_f32(const float* A, const float* B, int64_t K, int32_t m, int32_t n, float* C, int32_t accumulate,
                       float* scratch, size_t scratch_floats, void* stream) {
     if (!A || !B || !C || !scratch) return NOCF_E_NULL;
-    if (K < 1 || m < 1 || n < 1 || m > 64 || n > 64) return NOCF_E_SHAPE;
+    if (K < 1 || m < 1 || n < 1 || m > 512 || n > 512) return NOCF_E_SHAPE;
+    const int tiles_i = (m + 63) / 64, tiles_j = (n + 63) / 64, ntiles = tiles_i * tiles_j;
+    if (ntiles > 64) return NOCF_E_SHAPE;
     long nblocks = (K + 255) / 256;                       // >= 256 rows per workgroup
-    if (nblocks > 1024) nblocks = 1024;
-    if ((size_t)nblocks * 4096 > scratch_floats) nblocks = (long)(scratch_floats / 4096);
+    if (nblocks > 1024 / ntiles) nblocks = 1024 / ntiles;
+    if ((size_t)nblocks * ntiles * 4096 > scratch_floats) nblocks = (long)(scratch_floats / ((size_t)ntiles * 4096));
     if (nblocks < 1) return NOCF_E_WORKSPACE;
     long rpb = (K + nblocks - 1) / nblocks;
     rpb = (rpb + CT_ROWS - 1) / CT_ROWS * CT_ROWS;
     nblocks = (K + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(contract_partial_kernel, dim3((int)nblocks), dim3(256), 0, st, A, B, (long)K, m, n, rpb, scratch);
-    hipLaunchKernelGGL(contract_reduce_kernel, dim3((m * 64 + 15) / 16), dim3(256), 0, st, scratch, (int)nblocks, m, n, C, accumulate);
+    hipLaunchKernelGGL(contract_partial_kernel, dim3((int)nblocks, ntiles), dim3(256), 0, st, A, B, (long)K, m, n, rpb, tiles_j, scratch);
+    hipLaunchKernelGGL(contract_reduce_kernel, dim3(256, ntiles), dim3(256), 0, st, scratch, (int)nblocks, m, n, tiles_j, C, accumulate);
     return (int)hipGetLastError();
 }
 

@@ -29,11 +29,12 @@ _SCRATCH = {}
 
 
 def _contract(X, Y, out=None):
-    """X' Y for row streams X [K, m], Y [K, n] (out += when given).  Small outputs (m, n <= 64: the 2-12 agent
-    networks) go to the library's two-launch contraction (a library GEMM with a 32x32 output runs on one workgroup:
-    0.4 ms each); wide ones are library GEMMs (hipBLASLt, near its fp32 peak for 512x512 outputs)."""
+    """X' Y for row streams X [K, m], Y [K, n] (out += when given).  Small and medium outputs (up to about 128 x 128:
+    everything but the 512-wide swarm50 network) go to the library's two-launch contraction -- a library GEMM with such
+    an output and 10^5..10^6 rows runs on a handful of workgroups (0.4-1.4 ms each); wide ones are library GEMMs
+    (hipBLASLt, near its fp32 peak for 512x512 outputs)."""
     m, n = X.shape[1], Y.shape[1]
-    if m > 64 or n > 64:
+    if m > 512 or n > 512 or m * n > 128 * 160:
         r = X.t() @ Y
         return r if out is None else out.add_(r)
     dev = X.device

@@ -628,7 +628,8 @@ def test_backward_on_a_time_segment_with_many_steps(golden_pretrained):
         assert (p.grad.cpu().double() - w).abs().max().item() <= 1e-3 * scale + 1e-6, k
 
 
-@pytest.mark.parametrize("K,m,n", [(1, 1, 1), (257, 32, 25), (5000, 16, 5), (40001, 64, 64), (1000, 1, 33), (333, 61, 3)])
+@pytest.mark.parametrize("K,m,n", [(1, 1, 1), (257, 32, 25), (5000, 16, 5), (40001, 64, 64), (1000, 1, 33), (333, 61, 3),
+                                   (20011, 128, 128), (3000, 128, 13), (9000, 1, 128), (700, 100, 97)])
 def test_small_output_contraction_kernel(K, m, n):
     """nocf_contract_f32 (the weight-gradient contraction of the small networks) against a float64 matmul; accumulate mode"""
     from neuraloc_amd.train import _contract
