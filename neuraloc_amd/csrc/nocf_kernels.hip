@@ -64,10 +64,11 @@ struct DevPlan {
     int pMB, pKQc;                   // column blocks per hidden phase / k-quads of the closing phase (diagnostic: halves)
     int ldsFloats;
     int lPW;                         // x-only cost partials formed in the shadow of the residual phases: [2 sets][T][2 waves][2]
+    int nAg, pad_;                   // agents of the problem the plan was made for (a literal in the specialised kernels)
 };
 
 static_assert(sizeof(DevPlan) % 4 == 0 && sizeof(DevPlan) / 4 <= 256, "plan copy is done by one 256-thread block");
-static_assert(sizeof(DevPlan) == 4 * 58 + 8 * 11, "no implicit padding: plans are compared with memcmp");
+static_assert(sizeof(DevPlan) == 4 * 60 + 8 * 11, "no implicit padding: plans are compared with memcmp");
 
 // ------------------------------------------------------------------------------------------
 // plan layout.  constexpr: the host builds the plan of any shape at run time; for the shapes named in
@@ -96,7 +97,7 @@ constexpr int plan_layout(int d, int m, int nTh, int r, int n_agents, int bwd, i
     if (d < 1 || m < 1 || nTh < 2 || nTh > MAX_NTH || r < 1 || r > d + 1 || r > ZQLD) return NOCF_E_SHAPE;
     if (n_agents > 255) return NOCF_E_SHAPE;
     DevPlan pl{};
-    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh; pl.bwd = bwd;
+    pl.d = d; pl.D1 = d + 1; pl.m = m; pl.r = r; pl.nTh = nTh; pl.bwd = bwd; pl.nAg = n_agents;
     pl.MB = cdiv(m, 64); pl.DB = cdiv(pl.D1, 64);
     pl.KQ1 = rup(cdiv(pl.D1, 4), HALF); pl.KQm = rup(cdiv(m, 4), HALF);
     // geometry: waves per workgroup and sample sub-tiles
@@ -939,7 +940,7 @@ __device__ __forceinline__ float pair_sum_cyclic(const float* __restrict__ x, in
 // while the phase is still waiting for its slowest wave.  Partials go to PW[t][wave & 1][0..1].
 __device__ __forceinline__ void physics_x_shadow(const Ctx& c, const DevPlan& pl, const DevProb& pb, int k, int set = 0) {
     if (c.wave >= 4) return;
-    const int N = pb.nAgents;
+    const int N = pl.nAg;                           // (= pb.nAgents; a compile-time constant in the specialised kernels)
     const int t = 2 * k + (c.wave >> 1), half = c.wave & 1;
     const int j0 = half * 64 + c.lane;
     const float* x = lds + pl.lSB + t * pl.LDs;
