@@ -75,14 +75,15 @@ def lib_for(d, m, nTh, r, n_agents):
     src = os.path.join(csrc, "nocf_kernels.hip")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        tmp = "%s.%d.tmp" % (so, os.getpid())
         inc = os.path.join(os.path.dirname(os.path.dirname(csrc)), "include")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNOCF_JIT_ONLY",
                "-DNOCF_XS_D=%d" % key[0], "-DNOCF_XS_M=%d" % key[1], "-DNOCF_XS_T=%d" % key[2], "-DNOCF_XS_R=%d" % key[3],
-               "-DNOCF_XS_A=%d" % key[4], "-I" + inc, "-I" + csrc, "-o", so + ".tmp", src]
+               "-DNOCF_XS_A=%d" % key[4], "-I" + inc, "-I" + csrc, "-o", tmp, src]
         print("[neuraloc_amd] NOCF_JIT=1: specialising the kernels for shape d=%d m=%d nTh=%d r=%d agents=%d (about a minute, once)" % key,
               file=sys.stderr, flush=True)
         subprocess.check_call(cmd)
-        os.replace(so + ".tmp", so)
+        os.replace(tmp, so)                       # atomic: ranks that compile the same shape at once do not clash
     L = _jit_libs[key] = _bind(C.CDLL(so))
     return L
 
