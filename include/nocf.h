@@ -167,6 +167,20 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
                          float* PHIb, float* lam0, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same adjoint for SMALL networks (nTh = 2, m <= 32, d+1 <= 32, Cross2D agents: the shapes the lane kernel of
+ * nocf_rollout_f32 takes), one wavefront per sample with every weight-gradient row in registers: nothing is streamed and
+ * nothing is left to contract.  Returns NOCF_E_SHAPE for any other shape (use nocf_rollout_bwd_f32 then).
+ *   gpart  device [n, nocf_small_grad_floats(d, m)]: per-sample gradient vectors
+ *          [dK0 (m x (d+1)) | db0 (m) | dK1 (m x m) | db1 (m) | dw (m) | dc.weight (d+1) | dc.bias (1) | dM ((d+1) x (d+1))],
+ *          dM = d/d(A'A) (dA = A (dM + dM')); the caller sums them over the samples
+ *   lam0   device [n, d] = dJc/dx0 (nullable)
+ */
+int64_t nocf_small_grad_floats(int32_t d, int32_t m);
+int nocf_rollout_bwd_small_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                               const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                               float* gpart, float* lam0, void* stream);
+
+/*
  * C[m, n] (+)= sum_k A[k, 0..m) (x) B[k, 0..n) for small outputs (m, n <= 512, at most 64 tiles of 64 x 64) and very many rows: the contraction of the rows that
  * nocf_rollout_bwd_f32 streams into the weight gradients of a SMALL network (what torch autograd does with one mm per
  * parameter in the backward of trainOC.py:173).  Two launches, deterministic.  Wider networks contract with library GEMMs.

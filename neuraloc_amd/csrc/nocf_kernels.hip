@@ -1595,6 +1595,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 #include "nocf_group.inc"
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
+#include "nocf_lane_bwd.inc"
 
 __global__ void store_group_plan_kernel(GroupPlan gp, float* ws, const float* cbp) {
     if (threadIdx.x < sizeof(GroupPlan) / 4) {
@@ -1753,6 +1754,44 @@ int nocf_debug_set_stamp_buffer(void* device_buf) {
 int nocf_cost_means_f32(const float* cost_sums, const float* alph, float* out, void* stream) {
     if (!cost_sums || !alph || !out) return NOCF_E_NULL;
     hipLaunchKernelGGL(cost_means_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cost_sums, alph[0], alph[3], alph[4], alph[5], out);
+    return (int)hipGetLastError();
+}
+
+int64_t nocf_small_grad_floats(int32_t d, int32_t m) {
+    const long D1 = d + 1;
+    return (long)m * D1 + m + (long)m * m + m + m + D1 + 1 + D1 * D1;
+}
+
+int nocf_rollout_bwd_small_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                               const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                               float* gpart, float* lam0, void* stream) {
+    int rc = check_phi(phi);
+    if (rc) return rc;
+    if (!alph || !s_all || !z_final || !hs || !gpart) return NOCF_E_NULL;
+    if (n < 1 || nt < 1) return NOCF_E_SHAPE;
+    if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
+    DevProb pb;
+    rc = fill_prob(prob, phi->d, &pb);
+    if (rc) return rc;
+    // eligibility = the forward lane kernel's, Cross2D agents only
+    if (!(phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 && pb.kind == NOCF_PROB_CROSS2D && pb.agentDim == 2 &&
+          pb.nAgents * 2 == phi->d && env_int("NOCF_LANE", 1) != 0))
+        return NOCF_E_SHAPE;
+    LaneBwdArgs la;
+    la.P = DevPhi{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
+    la.d = phi->d; la.m = phi->m; la.r = phi->r; la.nAg = pb.nAgents; la.cb = phi->cb;
+    la.sAll = s_all; la.zT = z_final; la.hs = hs; la.n = n; la.nt = nt; la.nstage = (stepper == NOCF_RK4) ? 4 : 1;
+    la.t1 = (float)t1; la.a0 = alph[0]; la.a3 = alph[3]; la.a4 = alph[4]; la.a5 = alph[5]; la.inv_n = (float)inv_n;
+    la.gpart = gpart; la.P_total = nocf_small_grad_floats(phi->d, phi->m); la.lam0 = lam0;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((n + 3) / 4);
+    const int MPsel = phi->m <= 16 ? 16 : 32;
+    const int DPsel = phi->d + 1 <= 8 ? 8 : (phi->d + 1 <= 16 ? 16 : 32);
+    if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] lane adjoint kernel\n");
+#define NOCF_LANEB_LAUNCH(MPV, DPV) hipLaunchKernelGGL((rollout_lane_bwd_kernel<MPV, DPV>), dim3(grid), dim3(256), 0, st, la, pb)
+    if (MPsel == 16) { if (DPsel == 8) NOCF_LANEB_LAUNCH(16, 8); else if (DPsel == 16) NOCF_LANEB_LAUNCH(16, 16); else NOCF_LANEB_LAUNCH(16, 32); }
+    else             { if (DPsel == 8) NOCF_LANEB_LAUNCH(32, 8); else if (DPsel == 16) NOCF_LANEB_LAUNCH(32, 16); else NOCF_LANEB_LAUNCH(32, 32); }
+#undef NOCF_LANEB_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -97,6 +97,36 @@ class _OCflowTrain(torch.autograd.Function):
         rows = (nt * nstage + 2) * n
         phi_st, keep1, ws = net._c_struct(n)
         prob_st, keep2 = prob._c_struct(dev)
+        hs = _step_sizes(ctx.tspan, nt).to(dev)
+        alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+        lam0 = torch.empty(n, d, device=dev) if ctx.x_needs_grad else None          # dJc/dx0, like autograd's x.grad
+        lib = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+        # small networks: the lane-style adjoint accumulates every gradient row in registers (one vector per sample)
+        P = int(lib.nocf_small_grad_floats(d, m))
+        gpart = torch.empty(n, P, device=dev) if (net.nTh == 2 and m <= 32 and D1 <= 32) else None
+        if gpart is not None:
+            with torch.cuda.device(dev):
+                rc = lib.nocf_rollout_bwd_small_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
+                                                    float(ctx.tspan[1]), alph_c, 1.0 / float(ctx.n_total), _lib.ptr(s_all),
+                                                    _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(gpart), _lib.ptr(lam0),
+                                                    _lib.stream_ptr(dev))
+            if rc == 0:
+                gv = gpart.sum(0)
+                o = 0
+                grads = {}
+                for name, shape in (("N.layers.0.weight", (m, D1)), ("N.layers.0.bias", (m,)), ("N.layers.1.weight", (m, m)),
+                                    ("N.layers.1.bias", (m,)), ("w.weight", (1, m)), ("c.weight", (1, D1)), ("c.bias", (1,)),
+                                    ("dM", (D1, D1))):
+                    cnt = 1
+                    for v_ in shape:
+                        cnt *= v_
+                    grads[name] = gv[o:o + cnt].reshape(shape)
+                    o += cnt
+                dM = grads.pop("dM")
+                grads["A"] = net.A.detach() @ (dM + dM.t())
+                return _OCflowTrain._finish(ctx, gJ, grads, lam0, net)
+            if rc != -2:                                               # NOCF_E_SHAPE: not a lane-kernel shape -> row streams below
+                _lib.check(rc, "nocf_rollout_bwd_small_f32")
         L = net.nTh - 1
         # every row the kernel does not write must be zero: the value block (last n rows) of Y / V / Ab / Gb
         Y, Ob, Wb = (torch.empty(rows, m, device=dev) for _ in range(3))
@@ -107,9 +137,6 @@ class _OCflowTrain(torch.autograd.Function):
         for t in (V, Ab):
             t[:, rows - n:].zero_()
         PHIb = torch.zeros(n, device=dev)
-        lam0 = torch.empty(n, d, device=dev) if ctx.x_needs_grad else None          # dJc/dx0, like autograd's x.grad
-        hs = _step_sizes(ctx.tspan, nt).to(dev)
-        alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         with torch.cuda.device(dev):
             rc = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents).nocf_rollout_bwd_f32(
                                                  C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
@@ -130,6 +157,10 @@ class _OCflowTrain(torch.autograd.Function):
         grads["c.bias"] = PHIb.sum().reshape(1)
         dM = _contract(Gb, Sx) + 0.5 * (sT * PHIb[:, None]).t() @ sT
         grads["A"] = net.A.detach() @ (dM + dM.t())
+        return _OCflowTrain._finish(ctx, gJ, grads, lam0, net)
+
+    @staticmethod
+    def _finish(ctx, gJ, grads, lam0, net):
         out = [gJ * grads[name] for name, _ in net.named_parameters()]
         if ctx.group is not None:
             from .distributed import allreduce_flat
