@@ -11,7 +11,10 @@
  *   - functions enqueue work on `stream` (a hipStream_t passed as void*, 0 = default
  *     stream) and return without synchronising; nothing is allocated or freed
  *   - return value: 0 ok; <0 argument error (NOCF_E_*); >0 a hipError_t
- *   - no exceptions, no aborts, no global mutable state
+ *   - no exceptions, no aborts.  Process-global state: the diagnostic environment knobs (NOCF_LANE, NOCF_FIXED,
+ *     NOCF_SLAB, NOCF_GROUP, NOCF_DEBUG ...) are read with getenv at each call (the tests toggle kernels with them); the measurement hooks nocf_profile_begin/_end and nocf_debug_set_* keep a list of HIP
+ *     events / a diagnostic buffer pointer and are NOT thread-safe.  The compute entry points themselves
+ *     keep no state between calls (the caller owns the workspace)
  */
 #ifndef NOCF_H
 #define NOCF_H

@@ -8,6 +8,8 @@ Stated fp32 tolerances (the reference's own fp32-vs-fp64 n
    batch means (Jc, cs)  : rel 1e-4 (abs 1e-6 for tiny terms)
    per-sample costs      : rel 1e-3 + abs 1e-3, isolated mask-flip outliers counted and bounded
 """
+import os
+
 import numpy as np
 import pytest
 import torch
