@@ -1593,6 +1593,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 }
 
 #include "nocf_group.inc"
+#include "nocf_slab.inc"
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
 #include "nocf_lane_bwd.inc"
@@ -1682,6 +1683,70 @@ static int make_group_plan(const DevPlan& base, int n_agents, int kind /* NOCF_P
 
 static size_t group_ws_bytes(const GroupPlan& gp) {
     return (size_t)(gp.oX + (long)gp.ngroups * gp.xStride) * sizeof(float);
+}
+
+// Slab (weight-stationary) plan: returns 0 and fills *out when the shape qualifies, else an NOCF_E_* code.
+static int make_slab_plan(const DevPlan& base, int n_agents, long n, SlabPlan* out) {
+    if (base.nTh != 2 || base.m != 64 * SL_G || base.D1 > 16 * SL_KBD || base.r > 16 || n < 1) return NOCF_E_SHAPE;
+    SlabPlan sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.pp = base;
+    DevPlan& pl = sp.pp;
+    const int NT = n > 16 * 32 ? 2 : 1, OWN = 2 * NT;
+    sp.NT = NT; sp.OWN = OWN;
+    sp.ngroups = (int)((n + 16 * NT - 1) / (16 * NT));
+    if (sp.ngroups > 32) return NOCF_E_SHAPE;                    // all workgroups must be resident at once (one per CU)
+    pl.T = OWN; pl.nwaves = 4;
+    int l = 0;
+    auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
+    sp.lUF = take(NT * SL_KBM * 256);
+    sp.lSF = take(NT * SL_KBD * 256);
+    sp.lK4 = take(SL_KBD * 4 * 256);
+    sp.lYF = take(NT * 4 * 256);
+    sp.lVO = take(192);
+    sp.lCW = take(16 * SL_KBD);
+    sp.lA = take(base.r * 160);
+    sp.lXN = take(OWN * base.ZLD);
+    sp.lPHIP = take(NT * 64);
+    pl.lSB = take(OWN * base.LDs);
+    pl.lG = take(OWN * base.GLD);
+    pl.lZQ = take(OWN * ZQLD);
+    pl.lZ0 = take(OWN * base.ZLD);
+    pl.lZA = take(OWN * base.ZLD);
+    pl.lDZ = pl.lZA;                                             // quadcopter only (never takes this kernel)
+    pl.lRED = take(64);
+    pl.lSC = take(OWN * std::max(1, n_agents) + 8);
+    pl.lPHI = take(4);
+    pl.lTRIG = take(4);
+    pl.lPT = take(4);
+    pl.lPW = take(2 * OWN);
+    pl.ldsFloats = l;
+    if ((size_t)l * 4 > 160 * 1024) return NOCF_E_LDS;
+    long o = base.oPlan + (long)rup((int)(sizeof(SlabPlan) / 4), 64);         // floats
+    const long nW = (long)SL_G * 4 * SL_KBM * 64, nK1 = (long)SL_G * 4 * SL_KBD * 64, nK4 = (long)SL_G * SL_KBD * 4 * 64;   // float4s
+    sp.oW2 = o / 4; o += nW * 4;
+    sp.oW3 = o / 4; o += nW * 4;
+    sp.oK1 = o / 4; o += nK1 * 4;
+    sp.oK4 = o / 4; o += nK4 * 4;
+    sp.oAZ = o / 4; o += (long)SL_KBD * 64 * 4;
+    sp.oFlags = o; o += rup(sp.ngroups * 4 * NT * SL_G * 4, 64);
+    sp.oErr = o; o += 64;
+    sp.oXcc = o; o += rup(sp.ngroups * SL_G, 64);
+    int x = 0;
+    auto xt = [&](int nfl) { int oo = x; x += rup(nfl, 64); return oo; };
+    sp.xU = xt(NT * SL_KBM * 256);
+    sp.xV = xt(NT * SL_KBM * 256);
+    sp.xG = xt(NT * SL_G * SL_KBD * 256);
+    sp.xS = xt(NT * SL_KBD * 256);
+    sp.xP = xt(NT * SL_G * 16);
+    sp.xStride = x;
+    sp.oX = o;
+    *out = sp;
+    return 0;
+}
+
+static size_t slab_ws_bytes(const SlabPlan& sp) {
+    return (size_t)(sp.oX + (long)sp.ngroups * sp.xStride) * sizeof(float);
 }
 
 static size_t plan_ws_bytes(const DevPlan& pl) {
@@ -1863,6 +1928,8 @@ size_t nocf_rollout_workspace_bytes(int32_t d, int32_t m, int32_t nTh, int64_t n
     size_t b = plan_ws_bytes(pl);
     GroupPlan gp;
     if (n > 0 && make_group_plan(pl, 1, NOCF_PROB_QUADCOPTER, n, &gp) == 0) b = std::max(b, group_ws_bytes(gp));   // LDS-lightest view; sizes of the exchange area do not depend on the problem
+    SlabPlan sp;
+    if (n > 0 && make_slab_plan(pl, 1, std::min<long>(n, 1024), &sp) == 0) b = std::max(b, slab_ws_bytes(sp));
     return b;
 }
 
@@ -1944,7 +2011,38 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) use_group = false;
         else if ((long)gp.ngroups * gp.G > 2L * cus) use_group = false;
     }
-    if (use_group) {
+    // weight-stationary slab kernel (nocf_slab.inc): wide two-layer networks on point-agent problems, plain rollouts of up
+    // to 1024 samples (32 groups x 8 workgroups, one workgroup per CU, all resident at once)
+    SlabPlan sp;
+    const int slab_knob = env_int("NOCF_SLAB", 1);
+    bool use_slab = !use_group && !s_all && !zFull && slab_knob != 0 && (slab_knob >= 2 || n <= 512) && pb.kind != NOCF_PROB_QUADCOPTER &&
+                    make_slab_plan(pl, pb.nAgents, n, &sp) == 0 && workspace_bytes >= slab_ws_bytes(sp);
+    if (use_slab) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) use_slab = false;
+        else if (64 * ((sp.ngroups + 7) / 8) > cus) use_slab = false;
+    }
+    if (use_slab) {
+        sp.pp.cb = phi->cb;
+        sp.fast = env_int("NOCF_SLAB_FAST", 1);
+        DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
+        hipLaunchKernelGGL(slab_pack_kernel, dim3(1024), dim3(256), 0, st, sp, P, ws);
+        e = hipMemsetAsync(ws + sp.oFlags, 0, (size_t)(sp.oX - sp.oFlags) * 4, st);            // flags + error word
+        if (e) return (int)e;
+        const size_t ldsBytes = (size_t)sp.pp.ldsFloats * 4;
+        const void* fk = (sp.NT == 2) ? reinterpret_cast<const void*>(rollout_slab_kernel<2>) : reinterpret_cast<const void*>(rollout_slab_kernel<1>);
+        e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
+        if (env_int("NOCF_DEBUG", 0))
+            fprintf(stderr, "[nocf] slab kernel: %d groups x %d members, %d tile(s) of 16 samples, LDS %zu B/workgroup\n", sp.ngroups, SL_G, sp.NT, ldsBytes);
+        if (g_prof_on) {
+            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+            (void)hipEventRecord(ev0, st);
+        }
+        const SlabPlan* spp = reinterpret_cast<const SlabPlan*>(ws + sp.pp.oPlan);
+        void* args[] = {(void*)&spp, (void*)&pb, (void*)&ws, (void*)&ra};
+        e = hipLaunchKernel(fk, dim3(64 * ((sp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st); if (e) return (int)e;
+        errp = reinterpret_cast<const unsigned*>(ws) + sp.oErr;
+    } else if (use_group) {
         gp.pp.cb = phi->cb;
         hipLaunchKernelGGL(store_group_plan_kernel, dim3(1), dim3(256), 0, st, gp, ws, phi->cb_dev);
         const size_t zbytes = (size_t)(gp.oX - gp.oFlags) * 4;                 // flags + error word

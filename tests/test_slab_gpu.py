@@ -1,0 +1,136 @@
+"""GPU parity tests of the weight-stationary slab kernel (neuraloc_amd/csrc/nocf_slab.inc): wide two-layer
+networks (m = 512) on point-agent problems.  Checked against the oracle, against the reference's stored outputs
+(swarm50 fixture) and against the per-tile kernel (NOCF_SLAB=0) on the same inputs.
+
+Tolerances as in test_hip_parity.py: per-sample costs rel 1e-3 + abs 1e-3 (mask flips counted), means rel 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+import neuraloc_amd as na
+from oracle import ocflow_oracle as orc
+from conftest import load_golden
+from util_hip import closed_form_normal, make_net, make_oracle, make_prob
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+ALPH = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+
+
+def _synth_state_dict(nTh, m, d, seed):
+    """closed-form weights (no RNG): entries s*sin(a i + b j + phase), s ~ 1/sqrt(fan_in)"""
+    def fill(rows, cols, a, b, ph, s):
+        i = torch.arange(rows, dtype=torch.float64).unsqueeze(1)
+        j = torch.arange(cols, dtype=torch.float64).unsqueeze(0)
+        return (s * torch.sin(a * i + b * j + ph)).float()
+    r = min(10, d + 1)
+    sd = {"A": fill(r, d + 1, 0.37, 0.11, 0.1 + seed, 1.0 / (d + 1) ** 0.5),
+          "c.weight": fill(1, d + 1, 0.0, 0.23, 0.4 + seed, 0.3), "c.bias": torch.tensor([0.05]),
+          "w.weight": 1.0 + fill(1, m, 0.0, 0.31, 0.7 + seed, 0.2),
+          "N.layers.0.weight": fill(m, d + 1, 0.41, 0.13, 0.2 + seed, 1.0 / (d + 1) ** 0.5),
+          "N.layers.0.bias": fill(1, m, 0.0, 0.19, 0.3 + seed, 0.1).reshape(m)}
+    for l in range(1, nTh):
+        sd[f"N.layers.{l}.weight"] = fill(m, m, 0.29 + 0.01 * l, 0.17, 0.5 + seed + l, 1.0 / m ** 0.5)
+        sd[f"N.layers.{l}.bias"] = fill(1, m, 0.0, 0.27, 0.6 + seed + l, 0.1).reshape(m)
+    return sd
+
+
+def _table(x, net, prob, tspan, nt, stepper, alph):
+    with torch.no_grad():
+        _, csn = na.OCflow(x, net, prob, tspan, nt, stepper, alph, noMean=True)
+    return torch.cat(csn, 1).cpu()
+
+
+def _flips(tab, want):
+    off = (tab.double() - want.double()).abs() > 1e-3 + 1e-3 * want.double().abs()
+    return int(off.any(dim=1).sum())
+
+
+def test_slab_kernel_is_the_default_for_swarm50(monkeypatch, capfd):
+    g = load_golden("swarm50")
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
+    x = g.t("x").to(DEV)
+    monkeypatch.setenv("NOCF_DEBUG", "1")
+    monkeypatch.delenv("NOCF_SLAB", raising=False)
+    _table(x, net, prob, [0.0, 1.0], 4, "rk4", g.meta["alph"])
+    torch.cuda.synchronize()
+    assert "slab kernel" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 17, 39, 100, 512, 513, 1000, 1024])
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_slab_matches_tile_kernel_and_oracle_on_swarm50(n, training, fast, monkeypatch):
+    """pretrained swarm50 network, batches that fill 1..32 groups with one or two sample tiles (ragged tails included);
+    both exchange forms (fast = the same-XCD form where the placement allows it, 0 = write-through everywhere).
+    A few of these states are chaotic at nt = 10 (a 1e-6 relative change of x moves their terminal cost by 2 %, in the
+    oracle too), so per-sample rows may differ between two correct fp32 evaluations: such rows are counted and bounded,
+    the batch means must agree."""
+    g = load_golden("swarm50")
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=training)
+    m = g.meta
+    x = (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 3)).contiguous()
+    nt = 10
+    monkeypatch.setenv("NOCF_SLAB", "2")                 # the slab kernel for every batch size it can take
+    monkeypatch.setenv("NOCF_SLAB_FAST", fast)
+    slab = _table(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"])
+    again = _table(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"])
+    assert torch.equal(slab, again), "slab kernel is not run-to-run deterministic"
+    monkeypatch.setenv("NOCF_SLAB", "0")
+    tile = _table(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"])
+    allowed = max(2, n // 128)
+    assert _flips(slab, tile) <= allowed, f"slab vs tile kernel: {_flips(slab, tile)} samples differ"
+    keep = ~((slab.double() - tile.double()).abs() > 1e-3 + 1e-3 * tile.double().abs()).any(dim=1)
+    for j in range(7):                                   # batch means over the rows that are not chaotic / mask-flipped
+        a, b = slab[keep, j].double().mean().item(), tile[keep, j].double().mean().item()
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, f"column {j}: mean {a} vs {b}"
+    if n <= 100:
+        P, S = make_oracle(g, training)
+        want = orc.persample_table(x, P, S, [0.0, 1.0], nt, "rk4", m["alph"])
+        assert _flips(slab, want) <= 2, f"slab vs oracle: {_flips(slab, want)} samples off"
+
+
+@pytest.mark.parametrize("name,stepper,tspan,training", [
+    ("swarm", "rk4", [0.0, 1.0], False), ("swarm", "rk1", [0.0, 1.0], True), ("midcross20", "rk4", [0.25, 0.9], True),
+    ("swap12", "rk4", [0.0, 1.0], False), ("softcorridor", "rk4", [0.0, 1.0], True), ("swap2", "rk1", [0.1, 0.7], False),
+    ("midcross30", "rk4", [0.0, 1.0], False), ("hardcorridor", "rk4", [0.0, 1.0], False)])
+def test_slab_on_other_point_agent_problems(name, stepper, tspan, training):
+    """m = 512 networks (closed-form weights) on Cross2D / SwarmTraj problems of other dimensions: d+1 from 5 to 97"""
+    if name not in na.initProb.__globals__["PROBLEM_NAMES"]:
+        pytest.skip("not an initProb problem")
+    torch.manual_seed(11)
+    prob, x0, _, _ = na.initProb(name, 37, 8, 0.5, ALPH, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    d = x0.shape[1]
+    sd = _synth_state_dict(2, 512, d, seed=d % 5)
+    net = na.Phi(nTh=2, m=512, d=d, alph=ALPH)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    P = orc.PhiParams.from_state_dict(sd)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    nt = 5
+    got = _table(x0, net, prob, tspan, nt, stepper, ALPH)
+    want = orc.persample_table(x0.cpu(), P, S, tspan, nt, stepper, ALPH)
+    assert _flips(got, want) <= (2 if training else 1), f"{name}: {_flips(got, want)} samples off"
+    with torch.no_grad():
+        Jc, cs = na.OCflow(x0, net, prob, tspan, nt, stepper, ALPH)
+    for j in range(7):
+        assert abs(float(cs[j]) - got[:, j].double().mean().item()) <= 2e-6 * abs(float(cs[j])) + 1e-9
+
+
+def test_slab_full_size_against_reference(monkeypatch):
+    """BASELINE size (n = 1024, nt = 80) on the pretrained network: the reference's stored means"""
+    from util_hip import full_states
+    g = load_golden("swarm50")
+    if not g.has("full/Jc"):
+        pytest.skip("no full-size entry")
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
+    x = full_states(g, int(g["full/seed"])).to(DEV)
+    monkeypatch.setenv("NOCF_SLAB", "2")
+    with torch.no_grad():
+        Jc, cs = na.OCflow(x, net, prob, [0.0, 1.0], g.meta["nt"], "rk4", g.meta["alph"])
+    assert abs(float(Jc) - float(g["full/Jc"])) <= 1e-4 * abs(float(g["full/Jc"]))
+    for j in range(7):
+        want = float(g["full/cs"][j])
+        assert abs(float(cs[j]) - want) <= 1e-4 * abs(want) + 1e-6
