@@ -1687,7 +1687,7 @@ static size_t group_ws_bytes(const GroupPlan& gp) {
 
 // Slab (weight-stationary) plan: returns 0 and fills *out when the shape qualifies, else an NOCF_E_* code.
 static int make_slab_plan(const DevPlan& base, int n_agents, long n, SlabPlan* out) {
-    if (base.nTh != 2 || base.m != 64 * SL_G || base.D1 > 16 * SL_KBD || base.r > 16 || n < 1) return NOCF_E_SHAPE;
+    if (base.nTh != 2 || base.m != 64 * SL_G || base.D1 > 16 * SL_KBD || base.r > 16 || n < 1 || n_agents > 64) return NOCF_E_SHAPE;
     SlabPlan sp;
     memset(&sp, 0, sizeof(sp));
     sp.pp = base;
@@ -1705,7 +1705,7 @@ static int make_slab_plan(const DevPlan& base, int n_agents, long n, SlabPlan* o
     sp.lYF = take(NT * 4 * 256);
     sp.lVO = take(192);
     sp.lCW = take(16 * SL_KBD);
-    sp.lA = take(base.r * 160);
+    sp.lA = take(SL_KBD * 256);
     sp.lXN = take(OWN * base.ZLD);
     sp.lPHIP = take(NT * 64);
     pl.lSB = take(OWN * base.LDs);
@@ -1729,15 +1729,15 @@ static int make_slab_plan(const DevPlan& base, int n_agents, long n, SlabPlan* o
     sp.oK1 = o / 4; o += nK1 * 4;
     sp.oK4 = o / 4; o += nK4 * 4;
     sp.oAZ = o / 4; o += (long)SL_KBD * 64 * 4;
-    sp.oFlags = o; o += rup(sp.ngroups * 4 * NT * SL_G * 4, 64);
+    sp.oFlags = o; o += 64;
     sp.oErr = o; o += 64;
     sp.oXcc = o; o += rup(sp.ngroups * SL_G, 64);
     int x = 0;
     auto xt = [&](int nfl) { int oo = x; x += rup(nfl, 64); return oo; };
-    sp.xU = xt(NT * SL_KBM * 256);
-    sp.xV = xt(NT * SL_KBM * 256);
-    sp.xG = xt(NT * SL_G * SL_KBD * 256);
-    sp.xS = xt(NT * SL_KBD * 256);
+    sp.xU = xt(2 * NT * SL_KBM * 256);                          // [parity][tile][k-block] fragments
+    sp.xV = xt(2 * NT * SL_KBM * 256);
+    sp.xG = xt(2 * NT * SL_G * SL_KBD * 256);                   // [parity][tile][member][dim tile]
+    sp.xS = xt(2 * NT * SL_KBD * 256);
     sp.xP = xt(NT * SL_G * 16);
     sp.xStride = x;
     sp.oX = o;
@@ -2027,7 +2027,9 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         sp.fast = env_int("NOCF_SLAB_FAST", 1);
         DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
         hipLaunchKernelGGL(slab_pack_kernel, dim3(1024), dim3(256), 0, st, sp, P, ws);
-        e = hipMemsetAsync(ws + sp.oFlags, 0, (size_t)(sp.oX - sp.oFlags) * 4, st);            // flags + error word
+        e = hipMemsetAsync(ws + sp.oFlags, 0, (size_t)(sp.oX - sp.oFlags) * 4, st);            // error word, XCC id table
+        if (e) return (int)e;
+        e = hipMemsetAsync(ws + sp.oX, 0xFF, (size_t)sp.ngroups * sp.xStride * 4, st);         // every exchange word starts as the sentinel
         if (e) return (int)e;
         const size_t ldsBytes = (size_t)sp.pp.ldsFloats * 4;
         const void* fk = (sp.NT == 2) ? reinterpret_cast<const void*>(rollout_slab_kernel<2>) : reinterpret_cast<const void*>(rollout_slab_kernel<1>);

@@ -16,9 +16,9 @@ import bench                                   # noqa: E402
 import neuraloc_amd as na                      # noqa: E402
 from neuraloc_amd import _lib                  # noqa: E402
 
-NAMES = ["wait S", "gather S + barrier", "P1 gemm", "P1 epilogue + store", "publish: drain + flag (U, V, G)", "z = A s",
-         "wait U / wait V", "gather U/V + barrier", "P2 + P3 gemm", "P2 epilogue + store", "P3 epilogue + P4 + store",
-         "wait G + reduce + RK + S + costs"]
+NAMES = ["wait S + gather S + barrier", "P1: gemm, z, epilogue, store, publish", "wait U + gather + barrier", "P2: gemm .. publish",
+         "wait V + gather + barrier", "P3 + P4: gemm .. publish", "wait G", "reduce + RK + store S | x-costs (waves 2,3)", "publish S",
+         "barrier after publish S", "sum p^2 + costs + copy", "(loop top)"]
 
 
 def main():
