@@ -2032,7 +2032,9 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         e = hipMemsetAsync(ws + sp.oX, 0xFF, (size_t)sp.ngroups * sp.xStride * 4, st);         // every exchange word starts as the sentinel
         if (e) return (int)e;
         const size_t ldsBytes = (size_t)sp.pp.ldsFloats * 4;
-        const void* fk = (sp.NT == 2) ? reinterpret_cast<const void*>(rollout_slab_kernel<2>) : reinterpret_cast<const void*>(rollout_slab_kernel<1>);
+        const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
+        const void* fk = (sp.NT == 2) ? (c2 ? reinterpret_cast<const void*>(rollout_slab_kernel<2, 2>) : reinterpret_cast<const void*>(rollout_slab_kernel<2, 3>))
+                                      : (c2 ? reinterpret_cast<const void*>(rollout_slab_kernel<1, 2>) : reinterpret_cast<const void*>(rollout_slab_kernel<1, 3>));
         e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
         if (env_int("NOCF_DEBUG", 0))
             fprintf(stderr, "[nocf] slab kernel: %d groups x %d members, %d tile(s) of 16 samples, LDS %zu B/workgroup\n", sp.ngroups, SL_G, sp.NT, ldsBytes);
