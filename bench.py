@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- OCflow rollout throughput on MI355X (the metric BASELINE.json names).
 
-  python bench.py --gpus N --steps K --warmup W [--workload swarm50]
+  python bench.py --gpus N --steps K --warmup W [--workload swarm50] [--scaling strong|weak] [--n ROWS]
 
-A "step" is one OCflow call (non-intermediates: returns Jc and the 7 costs) over one batch of
-synthetic states already resident in HBM.  Default workload = the configuration north_star
-quotes its target on: swarm50 (true d=150, m=512, nTh=2), nt=80, n=1024 per GPU, fp32, RK4,
-prob.eval().  Weights are the reference's pretrained swarm50 network exported to
-tests/golden/swarm50.npz; states are xInit + var0 * (closed-form pseudo-normal table).
+A "step" is one public `OCflow(x, Phi, prob, [0,1], nt, "rk4", alph)` call (non-intermediates: returns Jc and the 7
+costs) over a batch of synthetic states already resident in HBM.  Default workload = the configuration north_star
+quotes its target on: swarm50 (true d=150, m=512, nTh=2), nt=80, GLOBAL n=1024, fp32, RK4, prob.eval().  Weights are
+the reference's pretrained swarm50 network exported to tests/golden/swarm50.npz; states are xInit + var0 * (closed-form
+pseudo-normal table).
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL); the batch shards by rows,
-every rank integrates its own 1024 samples (weak scaling) and one SUM all-reduce of 8 floats
-per call forms the global means.  value = total trajectories / max-over-ranks wall time.
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  Default = STRONG scaling, the partition north_star
+asks for: the global batch of n_train rows is split contiguously over the ranks (`shard_rows`), every rank integrates
+its n/N rows and ONE SUM all-reduce of 8 floats per call forms the global means (src/OCflow.py:80-86 takes them over
+the whole batch).  `--scaling weak` gives every rank its own n rows instead.  value = global trajectories / max-over-
+ranks wall time.  `--n` (N=1) with 512/256/128 rows is the single-GPU proxy for the per-rank work at 2/4/8 GPUs.
 
-One JSON line on stdout (rank 0), with `roofline` (rollout kernel, fp32-MFMA roof, duration
-from HIP events recorded around the kernel on its launch stream) and `cpu_baseline` (the oracle
--- the op-for-op eager-PyTorch port of the reference -- timed on the host cores, rank 0, N=1).
+`--workload singlequad-shock` is BASELINE config 5: 9 shock times x 4096 quadcopter states, two-segment rollouts with
+trajectories and controls kept (neuraloc_amd.shock); it prints its own JSON line.
+
+One JSON line on stdout (rank 0), with `roofline` (rollout kernel, fp32-MFMA roof, duration from HIP events recorded
+around the kernel on its launch stream) and `cpu_baseline` (the oracle -- the op-for-op eager-PyTorch port of the
+reference -- timed on the host cores, rank 0, N=1).
 """
 import argparse
 import ctypes as C
@@ -32,8 +37,7 @@ sys.path.insert(0, REPO)
 
 import neuraloc_amd as na                      # noqa: E402
 from neuraloc_amd import _lib                  # noqa: E402
-from neuraloc_amd.OCflow import _launch, costs_from_sums   # noqa: E402
-from neuraloc_amd.distributed import reduce_cost_sums      # noqa: E402
+from neuraloc_amd.distributed import OCflow_sharded, shard_rows   # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
 PEAK_HBM_GBS = 8000.0
@@ -62,6 +66,19 @@ def make_states(meta, xInit, n, seed):
     return (xInit + meta["var0"] * xi).contiguous()
 
 
+def build_objects(meta, sd, xtarget, dev):
+    net = na.Phi(nTh=meta["nTh"], m=meta["m"], d=meta["d"], alph=meta["alph"])
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    cls = {"Cross2D": na.Cross2D, "SwarmTraj": na.SwarmTraj, "Quadcopter": na.Quadcopter}[meta["prob_class"]]
+    if meta["prob_class"] == "Quadcopter":
+        prob = cls(xtarget.to(dev), obstacle=None, alph_Q=meta["alph_Q"], alph_W=meta["alph_W"])
+    else:
+        prob = cls(xtarget.to(dev), obstacle=meta["obstacle"], alph_Q=meta["alph_Q"], alph_W=meta["alph_W"], r=meta["r"])
+    prob.eval()
+    return net, prob
+
+
 def flops_per_state_step(meta):
     """4 RHS evaluations x [4m(d+1) + 4m^2(nTh-1) + 4r(d+1)] (problem terms excluded)"""
     d, m, nTh = meta["d"], meta["m"], meta["nTh"]
@@ -69,52 +86,113 @@ def flops_per_state_step(meta):
     return 4 * (4 * m * (d + 1) + 4 * m * m * (nTh - 1) + 4 * r * (d + 1))
 
 
-def cpu_baseline(meta, sd, xtarget, x, nt, budget_s=25.0):
-    """the oracle (checker / CPU port of the reference) timed on the host cores of this box.
-    Eager PyTorch on ~400 small ops per RHS evaluation does not scale to every core of a big host, so a
-    short probe (nt=2) picks the best intra-op thread count first; the figure reported is the full
-    workload at that count (`cores`), and the probe table is kept in `sample`."""
+def cpu_baseline(meta, sd, xtarget, x, nt, budget_s=60.0):
+    """The oracle (checker / CPU port of the reference) timed on the host cores of this box, SURVEY 8(d) protocol on a
+    BOUNDED sample: the same batch, the first few of the nt RK4 steps at the same step size h (every step costs the same
+    ~1 850 eager ops, so trajectories/s of the full rollout = n / (t_sample * nt / steps)).  Legs: 1 intra-op thread, all host
+    cores, and the best of a thread-count probe (eager PyTorch on ~460 small ops per RHS evaluation does not scale to every
+    core of a big host: at 256 threads it is slower than at 1).  Each leg: 3 warm-up steps, median of 3 timed calls, the number
+    of steps per call sized to ~1/6 of the time budget; a thread count whose single step already takes longer than 8 s is
+    reported from that one step.  The headline value is the best leg."""
     from oracle import ocflow_oracle as orc
     kind = {"Cross2D": orc.KIND_CROSS2D, "SwarmTraj": orc.KIND_SWARM, "Quadcopter": orc.KIND_QUAD}[meta["prob_class"]]
     P = orc.PhiParams.from_state_dict(sd)
     S = orc.ProbSpec(kind, xtarget, meta["obstacle"], meta["alph_Q"], meta["alph_W"], meta["r"], training=False)
     ncpu = os.cpu_count() or 1
-    # eager PyTorch collapses far beyond 64 threads on these shapes (256 threads: < 1 traj/s), so the probe stops at 64
-    cands = sorted({c for c in (1, 4, 8, 16, 32, 64, min(ncpu, 64)) if c <= ncpu})
-    probe = {}
+    n = x.shape[0]
+
+    def call(threads, steps):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        orc.rollout(x, P, S, [0.0, steps / nt], steps, "rk4", meta["alph"])
+        return time.perf_counter() - t0
+
+    notes = []
     with torch.no_grad():
-        for th in cands:
-            torch.set_num_threads(th)
-            orc.rollout(x, P, S, [0.0, 1.0], 1, "rk4", meta["alph"])
-            t0 = time.perf_counter()
-            orc.rollout(x, P, S, [0.0, 1.0], 2, "rk4", meta["alph"])
-            probe[th] = time.perf_counter() - t0
-        best = min(probe, key=probe.get)
-        torch.set_num_threads(best)
-        est = probe[best] * nt / 2.0
-        reps = max(1, min(5, int(budget_s / max(est, 1e-3))))
-        times = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            Jc, _ = orc.rollout(x, P, S, [0.0, 1.0], nt, "rk4", meta["alph"])
-            times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    table = ", ".join(f"{k}t:{x.shape[0] * 2 / nt / v:.0f}" for k, v in probe.items())
-    return {"value": x.shape[0] / med, "unit": "trajectories/s", "cores": best, "kind": "port",
-            "sample": f"full workload n={x.shape[0]} nt={nt}, median of {len(times)} call(s) at the best of the probed "
-                      f"intra-op thread counts (probe nt=2, traj/s-equivalent per count: {table}); eager PyTorch "
-                      f"{torch.__version__}, os.cpu_count()={ncpu}",
-            "seconds_per_call": med, "Jc": float(Jc)}
+        step_s = {}                                      # seconds per RK4 step by thread count (probe: second of two 1-step calls)
+        for th in sorted({c for c in (1, 4, 8, 16, 32, 64, ncpu) if c <= ncpu}):
+            first = call(th, 1)
+            step_s[th] = first if first > 8.0 else call(th, 1)
+            if step_s[th] > 8.0:
+                notes.append(f"{th} threads: one step took {step_s[th]:.1f} s, larger counts not probed")
+                break
+        best = min(step_s, key=step_s.get)
+        legs = {}
+        for th in sorted({1, best, ncpu}):
+            if th not in step_s:                         # (all cores, beyond the point where the probe stopped)
+                legs[th] = (step_s[max(step_s)], 1, "not run: slower than the last probed count; that count's step time stands in")
+                continue
+            if step_s[th] > 8.0:
+                legs[th] = (step_s[th], 1, "one step, one call")
+                continue
+            steps = int(max(1, min(8, (budget_s / 6.0) / (3.0 * step_s[th]))))
+            for _ in range(3):
+                call(th, 1)                              # >= 3 warm-ups
+            legs[th] = (float(np.median([call(th, steps) for _ in range(3)])) / steps, steps, "3 warm-ups, median of 3 calls")
+    traj = {th: n / (v[0] * nt) for th, v in legs.items()}
+    head = max(traj, key=traj.get)
+    table = ", ".join(f"{k}t:{n / nt / v:.0f}" for k, v in step_s.items())
+    legtxt = "; ".join(f"{th} thread(s): {v[1]} step(s)/call, {v[2]}" for th, v in legs.items())
+    return {"value": traj[head], "unit": "trajectories/s", "cores": head, "kind": "port",
+            "one_thread": traj[1], "all_cores": traj[ncpu], "all_cores_count": ncpu, "best_probe": traj[best], "best_probe_threads": best,
+            "sample": f"n={n} rows, the first steps of the {nt}-step RK4 rollout at the same h, scaled to {nt} steps; {legtxt}; "
+                      f"thread probe (1 step, traj/s-equivalent): {table}" + ("; " + "; ".join(notes) if notes else "")
+                      + f"; eager PyTorch {torch.__version__}",
+            "seconds_per_step": legs[head][0]}
+
+
+def read_traffic(workload, kernel, n_local):
+    """HBM bytes per launch from the PMC passes (tools/parse_pmc.py writes the file; rocprofv3 --pmc cannot run inside this
+    process).  Used only when it was collected for the same kernel and per-GPU batch; its provenance travels with it."""
+    tp = os.path.join(REPO, "profiles", f"hbm_traffic_{workload}.json")
+    if not os.path.exists(tp):
+        return None, None
+    try:
+        j = json.load(open(tp))
+    except Exception:
+        return None, None
+    if j.get("kernel_family") != kernel or int(j.get("n", -1)) != int(n_local):
+        return None, f"{os.path.relpath(tp, REPO)} is for kernel={j.get('kernel_family')} n={j.get('n')}: not this run"
+    return j.get("hbm_bytes_per_launch"), f"{os.path.relpath(tp, REPO)} ({j.get('source', '?')}, {j.get('collected', '?')})"
+
+
+def bench_shock(args, dev):
+    """BASELINE config 5: singlequad, 9 shock times x 4096 states x nt = 50, trajectories and controls kept"""
+    from neuraloc_amd.shock import shock_sweep
+    meta, sd, xtarget, xInit = load_workload("singlequad")
+    net, prob = build_objects(meta, sd, xtarget, dev)
+    n = args.n or meta["n_full"]
+    nt = args.nt or meta["nt"]
+    x = make_states(meta, xInit, n, seed=200).to(dev)
+    times = [0.1 * k for k in range(1, 10)]
+    shocks = torch.zeros(1, meta["d"], device=dev)
+    shocks[0, 0:3] = torch.tensor([0.5, -0.5, 0.25])
+    for _ in range(max(1, args.warmup)):
+        shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"metric": "shocked trajectories/sec (two-segment rollouts with trajectories and controls kept)",
+           "value": len(times) * n * args.steps / el, "unit": "trajectories/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic states; pretrained reference weights exported to npz",
+           "config": {"workload": f"singlequad-shock d={meta['d']} m={meta['m']} nt={nt} n={n} x {len(times)} shock times, rk4, eval-mode, fp32, "
+                                  "intermediates=True (zFull + ctrlFull written)", "Jc_last_segment": float(res[-1]["costs2"][0])}}
+    print(json.dumps(out), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", type=str, default="swarm50",
-                    choices=["swap2", "softcorridor", "swap12", "swarm50", "singlequad"])
-    ap.add_argument("--n", type=int, default=0, help="samples per GPU (default: the BASELINE.json n for the workload)")
+                    choices=["swap2", "softcorridor", "swap12", "swarm50", "singlequad", "singlequad-shock"])
+    ap.add_argument("--scaling", type=str, default="strong", choices=["strong", "weak"])
+    ap.add_argument("--n", type=int, default=0, help="batch rows: the GLOBAL batch (strong) or rows per GPU (weak); default: BASELINE.json's n")
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -140,31 +218,29 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.workload == "singlequad-shock":
+        assert world == 1, "the shock sweep is benchmarked on one GPU"
+        return bench_shock(args, dev)
+
     meta, sd, xtarget, xInit = load_workload(args.workload)
-    n = args.n or meta["n_full"]
+    n_arg = args.n or meta["n_full"]
     nt = args.nt or meta["nt"]
     alph = meta["alph"]
-    net = na.Phi(nTh=meta["nTh"], m=meta["m"], d=meta["d"], alph=alph)
-    net.load_state_dict(sd)
-    net = net.to(dev).eval()
-    cls = {"Cross2D": na.Cross2D, "SwarmTraj": na.SwarmTraj, "Quadcopter": na.Quadcopter}[meta["prob_class"]]
-    if meta["prob_class"] == "Quadcopter":
-        prob = cls(xtarget.to(dev), obstacle=None, alph_Q=meta["alph_Q"], alph_W=meta["alph_W"])
+    net, prob = build_objects(meta, sd, xtarget, dev)
+    if args.scaling == "strong":
+        n_global = n_arg
+        lo, hi = shard_rows(n_global, rank, world)
+        x_cpu = make_states(meta, xInit, n_global, seed=200)[lo:hi].contiguous()     # every rank: its rows of the SAME global batch
     else:
-        prob = cls(xtarget.to(dev), obstacle=meta["obstacle"], alph_Q=meta["alph_Q"], alph_W=meta["alph_W"], r=meta["r"])
-    prob.eval()
-    x_cpu = make_states(meta, xInit, n, seed=200 + rank)
+        n_global = n_arg * world
+        x_cpu = make_states(meta, xInit, n_arg, seed=200 + rank)
+    n_local = x_cpu.shape[0]
     x = x_cpu.to(dev)                                   # inputs resident in HBM before the timed region
 
-    host_reduce = world > 1 and os.environ.get("NOCF_BENCH_BACKEND", "nccl") != "nccl"
-
     def step():
-        _, sums, _, _ = _launch(x, net, prob, [0.0, 1.0], nt, "rk4", alph, False)
-        if host_reduce:                                  # gloo test mode: reduce on the host
-            sums = reduce_cost_sums(sums.cpu()).to(dev)
-        elif world > 1:
-            reduce_cost_sums(sums)                       # one RCCL all-reduce of 8 floats
-        return costs_from_sums(sums, alph)
+        if world > 1:
+            return OCflow_sharded(x, net, prob, [0.0, 1.0], nt, "rk4", alph)     # local rollout + one all-reduce of 8 floats
+        return na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph)
 
     L = _lib.lib()
     with torch.no_grad():
@@ -186,40 +262,37 @@ def main():
         kms, nl = C.c_double(0.0), C.c_int32(0)
         L.nocf_profile_end(C.byref(kms), C.byref(nl))
     if dist:
+        host_reduce = os.environ.get("NOCF_BENCH_BACKEND", "nccl") != "nccl"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_reduce else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     if rank == 0:
-        total_traj = world * n * args.steps
+        total_traj = n_global * args.steps
         value = total_traj / elapsed
         kernel_ms = kms.value / max(1, nl.value)
-        fl_launch = flops_per_state_step(meta) * n * nt
+        kernel = L.nocf_last_rollout_kernel().decode()
+        fl_launch = flops_per_state_step(meta) * n_local * nt
         achieved = fl_launch / (kernel_ms * 1e-3) / 1e12
-        alg_bytes = 8 * (meta["d"] + 4) * n * nt        # state in/out once per step
-        traffic = None
-        tp = os.path.join(REPO, "profiles", f"hbm_traffic_{args.workload}.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        alg_bytes = 8 * (meta["d"] + 4) * n_local * nt  # state in/out once per step
+        traffic, traffic_src = read_traffic(args.workload, kernel, n_local)
         out = {
             "metric": "trajectories/sec (n_train x nt states integrated)", "value": value, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic states (xInit + var0 * closed-form normal table); pretrained reference weights exported to npz",
             "config": {"workload": f"{args.workload} d={meta['d']} m={meta['m']} nTh={meta['nTh']} nt={nt} "
-                                   f"n={n}/GPU rk4 eval-mode fp32", "global_batch": world * n,
-                       "state_steps_per_s": value * nt, "parallelism": f"batch-sharded x{world}",
-                       "Jc": float(Jc)},
+                                   f"n={n_global} global ({n_local}/GPU) rk4 eval-mode fp32", "global_batch": n_global,
+                       "rows_per_gpu": n_local, "state_steps_per_s": value * nt,
+                       "parallelism": f"batch rows sharded x{world}, one 8-float SUM all-reduce per call", "Jc": float(Jc)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "rollout_kernel", "kernel_ms": kernel_ms, "launches_timed": nl.value,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "launches_timed": nl.value,
                          "algorithmic_flops_per_launch": fl_launch,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
                          "achieved_hbm_GBps_algorithmic": alg_bytes / (kernel_ms * 1e-3) / 1e9,
-                         "hbm_peak_GBps": PEAK_HBM_GBS},
+                         "hbm_peak_GBps": PEAK_HBM_GBS,
+                         "note": "per launch on rank 0: its rows x nt state-steps x SURVEY 8(d) FLOPs, over the kernel's HIP-event time"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(meta, sd, xtarget, x_cpu, nt)

@@ -90,6 +90,11 @@ typedef struct NocfProb {
 
 int nocf_version(void);
 
+/* measurement hook: name of the rollout kernel the last nocf_rollout_f32 / nocf_rollout_record_f32 call of this process
+ * launched ("rollout_slab_kernel", "rollout_kernel<shape-specialised>", "rollout_kernel<generic>", "rollout_lane_kernel",
+ * "rollout_group_kernel", or "none"); a static string, not thread-safe (bench.py labels its roofline with it) */
+const char* nocf_last_rollout_kernel(void);
+
 /* bytes of scratch `workspace` a call with these shapes needs (packed weight images) */
 size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh);
 

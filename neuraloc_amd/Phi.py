@@ -94,6 +94,7 @@ class Phi(nn.Module):
         st.cw = dv(self.c.weight, "c.weight")
         st.cb = 0.0
         st.cb_dev = dv(self.c.bias, "c.bias")           # read on the device: no device-to-host copy (a sync) per call
+        # (one workspace per module, repacked by every call: calls on the same Phi must be on one stream)
         nbytes = _lib.lib().nocf_rollout_workspace_bytes(self.d, self.m, self.nTh, int(n))
         if nbytes == 0:
             raise RuntimeError("nocf_workspace_bytes: unsupported (d, m, nTh)")
@@ -104,8 +105,8 @@ class Phi(nn.Module):
     def _guard_no_autograd(self, x, what):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
-                f"{what}: differentiating through the HIP path (trainOC's Jc.backward()) is the next scope row "
-                "(SURVEY.md section 8f); call under torch.no_grad()")
+                f"{what}: autograd through this stand-alone call is not built (no reference driver differentiates it); "
+                "Jc.backward() through OCflow(...) is -- neuraloc_amd/train.py.  Call under torch.no_grad()")
 
     def forward(self, x):
         """Phi(s), n-by-1 (src/Phi.py:91-96)."""

@@ -73,7 +73,9 @@ def lib_for(d, m, nTh, r, n_agents):
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libnocf_d%d_m%d_t%d_r%d_a%d.so" % key)
     src = os.path.join(csrc, "nocf_kernels.hip")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    deps = [src, os.path.join(os.path.dirname(os.path.dirname(csrc)), "include", "nocf.h")] + \
+           [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".inc")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         tmp = "%s.%d.tmp" % (so, os.getpid())
         inc = os.path.join(os.path.dirname(os.path.dirname(csrc)), "include")
@@ -90,6 +92,7 @@ def lib_for(d, m, nTh, r, n_agents):
 
 def _bind(L):
     L.nocf_version.restype = C.c_int
+    L.nocf_last_rollout_kernel.restype = C.c_char_p
     L.nocf_workspace_bytes.restype = C.c_size_t
     L.nocf_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.nocf_rollout_workspace_bytes.restype = C.c_size_t

@@ -11,10 +11,24 @@ from .Phi import Phi
 from .initProb import initProb
 
 
+def load_file(path, trusted=False):
+    """the {'args', 'state_dict'} dict of a checkpoint file.  The reference's files pickle an argparse.Namespace next to the
+    tensors; that one class is allow-listed for the weights-only unpickler, so loading a checkpoint cannot run code.
+    trusted=True (or NOCF_TRUST_CHECKPOINTS=1) falls back to the full unpickler for files that hold other objects."""
+    import os
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as exc:                              # noqa: BLE001 -- unpickling errors come in many types
+        if trusted or os.environ.get("NOCF_TRUST_CHECKPOINTS", "0") not in ("", "0"):
+            return torch.load(path, map_location="cpu", weights_only=False)
+        raise RuntimeError(f"{path}: not loadable with the weights-only unpickler ({exc}); if you trust the file, pass "
+                           "trusted=True or set NOCF_TRUST_CHECKPOINTS=1") from exc
+
+
 def load_checkpoint(path, device="cuda:0", n_train=None, n_val=None, var0=None):
-    """-> (net, prob, x0, x0v, xInit, args); `args` is the pickled Namespace (weights_only=False is required
-    for the reference's files on torch >= 2.6 because they pickle argparse.Namespace)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    """-> (net, prob, x0, x0v, xInit, args); `args` is the pickled Namespace (see load_file)"""
+    ck = load_file(path)
     a = ck["args"]
     alph = [float(v) for v in a.alph]
     dev = torch.device(device)

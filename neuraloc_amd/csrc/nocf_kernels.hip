@@ -1798,6 +1798,7 @@ static int check_phi(const NocfPhi* phi) {
 
 // ---- optional in-library timing of the rollout kernel (bench.py): HIP events recorded on the
 // launch stream immediately around the kernel, so the figure is the kernel's own duration.
+static const char* g_last_kernel = "none";           // measurement hook: which rollout kernel the last call launched (nocf_last_rollout_kernel)
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static bool g_prof_on = false;
 static unsigned long long* g_stamp_buf = nullptr;     // diagnostic builds only (nocf_debug_set_stamp_buffer)
@@ -1805,6 +1806,8 @@ static unsigned long long* g_stamp_buf = nullptr;     // diagnostic builds only 
 extern "C" {
 
 int nocf_version(void) { return NOCF_VERSION; }
+
+const char* nocf_last_rollout_kernel(void) { return g_last_kernel; }
 
 int nocf_debug_set_stamp_buffer(void* device_buf) {
 #ifdef NOCF_STAMPS
@@ -1990,6 +1993,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
 #undef NOCF_LANE_LAUNCH
         e = hipGetLastError();
         if (e) return (int)e;
+        g_last_kernel = "rollout_lane_kernel";
         if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
         if (cost_sums) {
             hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
@@ -2046,6 +2050,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         void* args[] = {(void*)&spp, (void*)&pb, (void*)&ws, (void*)&ra};
         e = hipLaunchKernel(fk, dim3(64 * ((sp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st); if (e) return (int)e;
         errp = reinterpret_cast<const unsigned*>(ws) + sp.oErr;
+        g_last_kernel = "rollout_slab_kernel";
     } else if (use_group) {
         gp.pp.cb = phi->cb;
         hipLaunchKernelGGL(store_group_plan_kernel, dim3(1), dim3(256), 0, st, gp, ws, phi->cb_dev);
@@ -2067,6 +2072,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         hipLaunchKernelGGL(rollout_group_kernel, dim3(gp.ngroups * gp.G), dim3(256), ldsBytes, st,
                            reinterpret_cast<const GroupPlan*>(ws + gp.pp.oPlan), pb, ws, ra);
         errp = reinterpret_cast<const unsigned*>(ws) + gp.oErr;
+        g_last_kernel = "rollout_group_kernel";
     } else {
         const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
         const int grid = (int)((n + pl.T - 1) / pl.T);
@@ -2091,9 +2097,11 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
                 void* args[] = {(void*)&plp, (void*)&pb, (void*)&ws, (void*)&ra};
                 e = hipLaunchKernel(fk, dim3(grid), dim3(block), args, ldsBytes, st); if (e) return (int)e;
                 launched = true;
+                g_last_kernel = "rollout_kernel<shape-specialised>";
                 if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] shape-specialised rollout kernel\n");
             }
         }
+        if (!launched) g_last_kernel = "rollout_kernel<generic>";
         if (!launched) switch (pl.T / 4) {
             case 1: e = set_lds(rollout_kernel<1, DynPlan>, ldsBytes); if (e) return (int)e;
                     hipLaunchKernelGGL((rollout_kernel<1, DynPlan>), dim3(grid), dim3(block), ldsBytes, st, plp, pb, ws, ra); break;

@@ -6,10 +6,13 @@ evalOC.py:113-122, softcorridor only there): nShock = int(t_s*nt) steps on [t0, 
 shocks at once (the BASELINE "singlequad shock-eval sweep"); both segments are the fused HIP rollout."""
 import torch
 
-from .OCflow import _launch, costs_from_sums
+from importlib import import_module
+
+_oc = import_module(__package__ + ".OCflow")           # the module, not the function the package re-exports under the same name
+from .OCflow import costs_from_sums
 
 
-def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, stepper="rk4"):
+def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, stepper="rk4", group=None, gather=False):
     """
     :param x:     nex-by-d initial states on the MI355X
     :param t_s:   shock time, tspan[0] < t_s < tspan[1], with int(t_s*nt) >= 1
@@ -20,6 +23,9 @@ def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, ste
         ctrl      the same concatenation for the controls
         costs1, costs2   (Jc, cs) of the two segments
         nShock
+    Sharded sweeps (BASELINE config 5): with `group` (a torch.distributed process group, or True for the default
+    one) x holds THIS RANK's rows of the batch (a nex-by-d `shock` too); the costs are the global-batch means (one all-reduce of
+    8 floats per segment) and traj / ctrl stay sharded by rows unless gather=True all-gathers them onto every rank.
     """
     alph = list(Phi.alph if alph is None else alph)
     d = x.shape[1]
@@ -30,16 +36,25 @@ def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, ste
     shock = torch.as_tensor(shock, dtype=x.dtype, device=x.device)
     # one launch per segment gives the trajectory, the controls AND the cost sums (the reference runs OCflow twice)
     with torch.no_grad():
-        _, sums1, zF1, cF1 = _launch(x, Phi, prob, [tspan[0], t_s], nShock, stepper, alph, True)
+        grp = None if group is True else group
+        if group is not None:
+            from .distributed import gather_rows, reduce_cost_sums
+        _, sums1, zF1, cF1 = _oc._launch(x, Phi, prob, [tspan[0], t_s], nShock, stepper, alph, True)
         z1, c1 = zF1.permute(1, 2, 0), cF1.permute(1, 2, 0)
+        if group is not None:
+            sums1 = reduce_cost_sums(sums1, grp)
         costs1 = costs_from_sums(sums1, alph)
         xs = (z1[:, :d, -1] + shock).contiguous()
         n2 = 1 + nt - nShock
-        _, sums2, zF2, cF2 = _launch(xs, Phi, prob, [t_s, tspan[1]], n2, stepper, alph, True)
+        _, sums2, zF2, cF2 = _oc._launch(xs, Phi, prob, [t_s, tspan[1]], n2, stepper, alph, True)
         z2, c2 = zF2.permute(1, 2, 0), cF2.permute(1, 2, 0)
+        if group is not None:
+            sums2 = reduce_cost_sums(sums2, grp)
         costs2 = costs_from_sums(sums2, alph)
-    return {"traj": torch.cat((z1[:, :d, :], z2[:, :d, :]), dim=2), "ctrl": torch.cat((c1, c2), dim=2),
-            "costs1": costs1, "costs2": costs2, "nShock": nShock, "x_shocked": xs}
+        traj, ctrl = torch.cat((z1[:, :d, :], z2[:, :d, :]), dim=2), torch.cat((c1, c2), dim=2)
+        if group is not None and gather:
+            traj, ctrl, xs = gather_rows(traj.contiguous(), grp), gather_rows(ctrl.contiguous(), grp), gather_rows(xs, grp)
+    return {"traj": traj, "ctrl": ctrl, "costs1": costs1, "costs2": costs2, "nShock": nShock, "x_shocked": xs}
 
 
 def shock_sweep(x, Phi, prob, nt, shock_times, shocks, **kw):

@@ -56,7 +56,19 @@ class _OCflowTrain(torch.autograd.Function):
     def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
         ctx.x_needs_grad = bool(x.requires_grad)
         x = _lib.require_device_f32(x.detach(), "x")
+        # the kernels index with Phi's d: a mismatching x would read and write out of bounds (same checks as OCflow._launch)
+        if x.dim() != 2:
+            raise ValueError("x must be nex-by-d")
         n, d = x.shape
+        if d != net.d:
+            raise ValueError(f"x has d={d} but Phi was built for d={net.d}")
+        if len(alph) < 6:
+            raise ValueError("alph needs 6 entries")
+        if int(nt) < 1:
+            raise ValueError("nt must be >= 1")
+        pd_ = getattr(prob, "d", None)
+        if pd_ is not None and int(pd_) != d:
+            raise ValueError(f"the problem object has d={pd_} but x has d={d}")
         dev = x.device
         phi_st, keep1, ws = net._c_struct(n)
         prob_st, keep2 = prob._c_struct(dev)
@@ -82,6 +94,8 @@ class _OCflowTrain(torch.autograd.Function):
                 n_total = int(round(float(sums[7].item())))
         ctx.n_total = n_total or n
         ctx.save_for_backward(s_all, z_out)
+        # the adjoint re-reads the weights from the module: they must still be the ones this forward ran with
+        ctx.param_versions = [p._version for p in net.parameters()]
         means = sums[:7] / sums[7]
         Jc = means[0] + alph[0] * means[1] + alph[3] * means[2] + alph[4] * means[3] + alph[5] * means[4]
         return Jc, means.detach()
@@ -90,6 +104,10 @@ class _OCflowTrain(torch.autograd.Function):
     def backward(ctx, gJ, _gmeans):
         s_all, z_out = ctx.saved_tensors
         net, prob, nt, alph = ctx.net, ctx.prob, ctx.nt, ctx.alph
+        if [p._version for p in net.parameters()] != ctx.param_versions:
+            raise RuntimeError("OCflow backward: a parameter of Phi was modified in place (optimizer step, load_state_dict) between "
+                               "this forward and its backward; the adjoint would run with weights that do not match the recorded "
+                               "stage inputs.  Call backward() before changing the parameters.")
         dev = s_all.device
         n, d = z_out.shape[0], z_out.shape[1] - 4
         m, D1 = net.m, d + 1

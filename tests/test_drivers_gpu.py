@@ -31,3 +31,67 @@ def test_short_training_run_and_checkpoint_roundtrip(tmp_path, capsys):
     with torch.no_grad():
         Jc, _ = na.OCflow(xInit, net.eval(), prob, [0.0, 1.0], 12, "rk4", net.alph)
     assert torch.isfinite(Jc) and best < float("inf")
+
+
+def test_evalOC_on_a_reference_checkpoint(tmp_path, capsys):
+    """evalOC.py with the reference's flag set on a checkpoint in the reference's layout (weights = the pretrained softcorridor
+    network of tests/golden/softcorridor.npz): the printed costs on xInit are the reference's known answers (SURVEY 8(c),
+    fixture xinit_eval/*), the deployment line has timeOC.py's format, the trajectory file and the shocked rollouts exist"""
+    import argparse
+    import re
+    import numpy as np
+    import evalOC
+    import neuraloc_amd as na
+    from neuraloc_amd.checkpoint import save_checkpoint
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from conftest import load_golden
+    g = load_golden("softcorridor")
+    m = g.meta
+    net = na.Phi(nTh=m["nTh"], m=m["m"], d=m["d"], alph=m["alph"])
+    net.load_state_dict(g.state_dict())
+    ck = os.path.join(str(tmp_path), "softcorridor_nn_checkpt.pth")
+    save_checkpoint(ck, net, argparse.Namespace(data="softcorridor", m=m["m"], nTh=m["nTh"], alph=m["alph"], n_train=64, var0=1.0))
+    save = os.path.join(str(tmp_path), "eval")
+    out = evalOC.main(["--resume", ck, "--nt", str(int(g["xinit_eval/nt"])), "--save", save, "--do_shock", "--batch", "64",
+                       "--alph", "1.0, 1.0, 1.0, 1.0, 1.0, 1.0", "--approach", "ocflow", "--prec", "single"])
+    text = capsys.readouterr().out
+    want_J, want_cs = float(g["xinit_eval/Jc"]), g["xinit_eval/cs"].astype(float)
+    assert abs(out["Jc"] - want_J) <= 1e-4 * abs(want_J)
+    for got, want in zip(out["cs"], want_cs):
+        assert abs(got - want) <= 1e-4 * abs(want) + 1e-6
+    # the reference's two log lines (evalOC.py:76-85): header, then L+G, L, a0 G, a3 HJt, a4 HJfin, a5 HJgrad, Q, W
+    assert "just xInit" in text and "HJgrad" in text
+    a = m["alph"]
+    row = "         {:12.4e} {:11.3e} {:11.3e} {:11.3e} {:11.3e} {:11.3e} {:11.3e} {:11.3e}".format(
+        want_cs[0] + a[0] * want_cs[1], want_cs[0], a[0] * want_cs[1], a[3] * want_cs[2], a[4] * want_cs[3], a[5] * want_cs[4], want_cs[5], want_cs[6])
+    got_row = [ln for ln in text.splitlines() if re.match(r"^\s+[-0-9.]+e[-+]\d+\s", ln)][0]
+    for gv, wv in zip(got_row.split(), row.split()):
+        assert abs(float(gv) - float(wv)) <= 2e-3 * abs(float(wv)) + 1e-9, (got_row, row)
+    assert re.search(r"^time: +[0-9.]+ +avg time / RK4 timestep: +[0-9.]+$", text, re.M), "timeOC.py:80 line format"
+    assert os.path.exists(os.path.join(save, "deploy_times"))
+    z = np.load(os.path.join(save, "figs", "eval_softcorridor_nn.npz"))        # the reference names its outputs basename[:-12]
+    assert z["zFull"].shape == (1, m["d"] + 4, int(g["xinit_eval/nt"]) + 1) and z["ctrlFull"].shape[1] == m["d"]
+    assert os.path.exists(os.path.join(save, "figs", "eval_softcorridor_nn_shock.npz"))
+    assert "majorshock at t=0.1" in text
+    with pytest.raises(SystemExit):
+        evalOC.main(["--resume", ck, "--prec", "double"])
+
+
+def test_training_path_validates_its_inputs_and_parameter_versions():
+    """the training entry checks x against the network like the evaluation entry does, and a backward after
+    the parameters changed raises instead of silently using the new weights"""
+    import neuraloc_amd as na
+    dev = torch.device("cuda:0")
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(0)
+    prob, x0, _, _ = na.initProb("softcorridor", 16, 16, 0.5, alph, lambda t: t.float().to(dev))
+    net = na.Phi(2, 16, 4, alph=alph).to(dev)
+    with pytest.raises(ValueError, match="d="):
+        na.OCflow(torch.zeros(16, 6, device=dev), net, prob, [0.0, 1.0], 4, "rk4", alph)
+    with pytest.raises(ValueError, match="alph"):
+        na.OCflow(x0, net, prob, [0.0, 1.0], 4, "rk4", alph[:3])
+    Jc, _ = na.OCflow(x0, net, prob, [0.0, 1.0], 4, "rk4", alph)
+    with torch.no_grad():
+        net.w.weight.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        Jc.backward()

@@ -64,3 +64,57 @@ def test_two_rank_training_matches_full_batch(name, tmp_path):
     scale = np.abs(full[1:]).max()
     assert abs(r0[0] - full[0]) <= 1e-5 * abs(full[0])
     assert np.abs(r0[1:] - full[1:]).max() <= 2e-5 * scale
+
+
+def _shock_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import neuraloc_amd as na
+    from neuraloc_amd.shock import shock_rollout
+    from conftest import load_golden
+    from util_hip import make_net, make_prob
+    dev = torch.device("cuda:0")
+    g = load_golden("singlequad")
+    net, prob = make_net(g, dev), make_prob(g, dev, training=False)
+    x = g.t("x")[:21].to(dev)                              # 21 rows over 2 ranks: shards of 11 and 10
+    lo, hi = na.shard_rows(x.shape[0], rank, world)
+    shock = torch.zeros(1, g.meta["d"], device=dev)
+    shock[0, :3] = torch.tensor([0.5, -0.5, 0.25])
+    with torch.no_grad():
+        res = shock_rollout(x[lo:hi].contiguous(), net, prob, 20, 0.3, shock, alph=g.meta["alph"], group=True, gather=True)
+        zF, cF = na.OCflow_sharded(x[lo:hi].contiguous(), net, prob, [0.0, 1.0], 12, "rk4", g.meta["alph"], intermediates=True, gather=True)
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), traj=res["traj"].cpu().numpy(), ctrl=res["ctrl"].cpu().numpy(),
+             J1=float(res["costs1"][0]), J2=float(res["costs2"][0]), zF=zF.cpu().numpy(), cF=cF.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_shock_sweep_on_the_gpu(tmp_path):
+    """SURVEY 8(e) / BASELINE config 5: shocked quadcopter rollouts and intermediates over a row-sharded batch through the
+    HIP kernels (uneven shards, all-gathered) equal the single-process result row for row"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import neuraloc_amd as na
+    from neuraloc_amd.shock import shock_rollout
+    from conftest import load_golden
+    from util_hip import make_net, make_prob
+    world = 2
+    mp.spawn(_shock_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    g = load_golden("singlequad")
+    net, prob = make_net(g, dev), make_prob(g, dev, training=False)
+    x = g.t("x")[:21].to(dev)
+    shock = torch.zeros(1, g.meta["d"], device=dev)
+    shock[0, :3] = torch.tensor([0.5, -0.5, 0.25])
+    with torch.no_grad():
+        want = shock_rollout(x, net, prob, 20, 0.3, shock, alph=g.meta["alph"])
+        zW, cW = na.OCflow(x, net, prob, [0.0, 1.0], 12, "rk4", g.meta["alph"], intermediates=True)
+    r0, r1 = np.load(tmp_path / "s0.npz"), np.load(tmp_path / "s1.npz")
+    for r in (r0, r1):
+        assert np.array_equal(r["traj"], want["traj"].cpu().numpy()), "per-sample trajectories do not depend on the sharding"
+        assert np.array_equal(r["ctrl"], want["ctrl"].cpu().numpy())
+        assert np.array_equal(r["zF"], zW.cpu().numpy()) and np.array_equal(r["cF"], cW.cpu().numpy())
+        for k, w in (("J1", want["costs1"][0]), ("J2", want["costs2"][0])):
+            assert abs(float(r[k]) - float(w)) <= 1e-5 * abs(float(w))

@@ -2,7 +2,9 @@
 """trainOC-style driver on the MI355X path.
 
 Same flags, log columns and checkpoint layout as the reference driver (trainOC.py:22-63 flags, :155-160 header,
-:176-196 iteration line, :199-207 checkpoint, :249-265 lr decay / resampling / alph switch); every OCflow call --
+:176-196 iteration line, :199-207 checkpoint, :249-265 lr decay / resampling / alph switch -- with ONE deliberate difference: at every lr decay the parameters really roll
+back to the best validated ones (the reference's reload is a no-op because its bestParams aliases the live tensors; --lr_reload alias
+reproduces that)); every OCflow call --
 forward, Jc.backward(), validation -- runs in the HIP kernels.  No plotting (viz_freq is accepted and ignored).
 
 One GPU:   python trainOC.py --data softcorridor --niters 200
@@ -38,6 +40,7 @@ _FLAGS = [
     ("gpu", int, 0, "device index of a single-process run"),
     ("prec", str, "single", "the HIP path is fp32"),
     ("approach", str, "ocflow", ""),
+    ("lr_reload", str, "clone", "(addition) clone: every lr_freq roll back to the best validated parameters; alias: the reference's no-op"),
     ("viz_freq", int, 100, "ignored: nothing is plotted"),
     ("val_freq", int, 25, "validate every this many iterations"),
     ("log_freq", int, 1, "print every this many iterations"),
@@ -91,7 +94,8 @@ def main(argv=None):
     d, m, nTh, tspan = x0.size(1), args.m, args.nTh, [0.0, 1.0]
     net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)
     if args.resume is not None:
-        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        from neuraloc_amd.checkpoint import load_file
+        ck = load_file(args.resume)
         m, nTh = ck["args"].m, ck["args"].nTh
         net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)                      # alph from the command line wins (trainOC.py:129)
         net.load_state_dict(ck["state_dict"])
@@ -144,7 +148,11 @@ def main(argv=None):
         if itr % args.log_freq == 0:
             say(line)
         if itr % args.lr_freq == 0 and best_params is not None:
-            net.load_state_dict(best_params)                             # back to the best parameters so far
+            # DELIBERATE DEVIATION (default): roll back to the best parameters so far.  In the reference, bestParams =
+            # net.state_dict() ALIASES the live tensors (trainOC.py:199), so its load_state_dict(bestParams) at lr_freq
+            # (:250-253) is a no-op; --lr_reload alias reproduces that for like-for-like convergence comparisons.
+            if args.lr_reload == "clone":
+                net.load_state_dict(best_params)
             for g in optim.param_groups:
                 g["lr"] *= args.lr_decay
         if itr % args.sample_freq == 0:
