@@ -2,7 +2,7 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass as MI355X_MICROARCH.md
 prescribes: they do not fit one TCC pass) into profiles/hbm_traffic_<workload>.json.
 
-usage: parse_pmc.py <fetch_dir> <write_dir> <workload> <out.json>
+usage: parse_pmc.py <fetch_dir> <write_dir> <workload> <out.json> [kernel_substring kernel_family n_rows source_tag]
 Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports half the bytes of a wide (16 B/lane) coalesced read stream, so the read side is doubled;
 WRITE_SIZE is exact for 16-B stores (our stores are 4-B per lane: uncalibrated, reported as is)."""
@@ -24,13 +24,19 @@ def per_launch(d, counter, kernel="rollout_kernel"):
 
 
 def main():
+    import datetime
     fd, wd, wl, out = sys.argv[1:5]
-    fetch = per_launch(fd, "FETCH_SIZE")
-    write = per_launch(wd, "WRITE_SIZE")
-    assert fetch and write, "no rollout_kernel rows found"
+    ksub = sys.argv[5] if len(sys.argv) > 5 else "rollout_kernel"
+    family = sys.argv[6] if len(sys.argv) > 6 else "rollout_kernel<shape-specialised>"     # what nocf_last_rollout_kernel() reports
+    nrows = int(sys.argv[7]) if len(sys.argv) > 7 else 1024
+    source = sys.argv[8] if len(sys.argv) > 8 else "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)"
+    fetch = per_launch(fd, "FETCH_SIZE", ksub)
+    write = per_launch(wd, "WRITE_SIZE", ksub)
+    assert fetch and write, "no rows of that kernel found"
     f_kib = sum(fetch) / len(fetch)
     w_kib = sum(write) / len(write)
-    rec = {"workload": wl, "kernel": "rollout_kernel", "launches": [len(fetch), len(write)],
+    rec = {"workload": wl, "kernel": ksub, "kernel_family": family, "n": nrows, "source": source,
+           "collected": datetime.date.today().isoformat(), "launches": [len(fetch), len(write)],
            "FETCH_SIZE_KiB_per_launch_raw": f_kib, "WRITE_SIZE_KiB_per_launch_raw": w_kib,
            "read_bytes_per_launch_corrected": 2.0 * f_kib * 1024.0, "write_bytes_per_launch": w_kib * 1024.0,
            "hbm_bytes_per_launch": 2.0 * f_kib * 1024.0 + w_kib * 1024.0,

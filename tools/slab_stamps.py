@@ -46,7 +46,7 @@ def main():
     mean = acc.mean(0)
     tot = mean.sum().item()
     evals = 4 * nt + 1
-    print(f"n={n}: {acc.shape[0]} workgroups, {tot:.0f} cycles per workgroup, {tot / evals:.0f} per evaluation (fast={os.environ.get('NOCF_SLAB_FAST', '0')})")
+    print(f"n={n}: {acc.shape[0]} workgroups, {tot:.0f} cycles per workgroup, {tot / evals:.0f} per evaluation (NOCF_SLAB_FAST={os.environ.get('NOCF_SLAB_FAST', '1 (default: same-XCD form where the placement allows)')})")
     for i, nm in enumerate(NAMES):
         print(f"  {nm:32s} {mean[i].item() / evals:9.0f} cyc/eval  {100 * mean[i].item() / tot:5.1f} %   (min {acc[:, i].min().item() / evals:7.0f}, max {acc[:, i].max().item() / evals:7.0f})")
 
