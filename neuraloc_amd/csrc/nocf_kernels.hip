@@ -1594,6 +1594,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 
 #include "nocf_group.inc"
 #include "nocf_slab.inc"
+#include "nocf_mono.inc"
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
 #include "nocf_lane_bwd.inc"
@@ -1747,6 +1748,66 @@ static int make_slab_plan(const DevPlan& base, int n_agents, long n, SlabPlan* o
 
 static size_t slab_ws_bytes(const SlabPlan& sp) {
     return (size_t)(sp.oX + (long)sp.ngroups * sp.xStride) * sizeof(float);
+}
+
+// Mono (one-CU weight-stationary) plan: returns 0 and fills *out when the shape has an instantiation, else an NOCF_E_* code.
+#define MONO_SHAPES(X) X(8, 1) X(4, 1) X(2, 1)
+static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out) {
+    if (base.nTh != 2 || base.r > 16) return NOCF_E_SHAPE;
+    const int KBD = cdiv(base.D1, 16);
+    int KBM = cdiv(base.m, 16);
+    KBM = KBM <= 2 ? 2 : (KBM <= 4 ? 4 : KBM);                 // hidden units are zero-padded up to an instantiated width
+    bool have = false;
+#define NOCF_MONO_HAVE(M_, D_) if (KBM == M_ && KBD == D_) have = true;
+    MONO_SHAPES(NOCF_MONO_HAVE)
+#undef NOCF_MONO_HAVE
+    if (!have) return NOCF_E_SHAPE;
+    MonoPlan mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.pp = base;
+    mp.KBM = KBM; mp.KBD = KBD;
+    DevPlan& pl = mp.pp;
+    const int T = 16;
+    pl.T = T; pl.nwaves = 4;
+    int l = 0;
+    auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
+    mp.lSF = take(KBD * 256);
+    mp.lUF = take(KBM * 256);
+    mp.lVF = take(KBM * 256);
+    mp.lK4 = take(KBD * KBM * 256);
+    mp.lAT = take(KBD * 256);
+    mp.lVO = take(3 * KBM * 16);
+    mp.lCW = take(KBD * 16);
+    mp.lZP = take(4 * 256);
+    mp.lGP = take(KBD * 4 * 256);
+    mp.lPHIP = take(64);
+    pl.lSB = take(T * base.LDs);
+    pl.lG = take(T * base.GLD);
+    pl.lZQ = take(T * ZQLD);
+    pl.lZ0 = take(T * base.ZLD); pl.lZA = take(T * base.ZLD); pl.lDZ = take(T * base.ZLD);
+    pl.lRED = take(std::max(T, 4) * 4);
+    pl.lSC = take(T * std::max(1, n_agents) + 8);
+    pl.lPHI = take(T);
+    pl.lTRIG = take(T * std::max(1, n_agents) * 6);
+    pl.lPT = take(4);
+    pl.lPW = take(4);
+    pl.ldsFloats = l;
+    if ((size_t)l * 4 > 64 * 1024) return NOCF_E_LDS;
+    long o = base.oPlan + (long)rup((int)(sizeof(MonoPlan) / 4), 64);         // floats
+    const long nW = (long)KBM * KBM * 64, nK1 = (long)KBM * KBD * 64, nK4 = (long)KBD * KBM * 64, nA = (long)KBD * 64;   // float4s
+    mp.oW2 = o / 4; o += nW * 4;
+    mp.oW3 = o / 4; o += nW * 4;
+    mp.oK1 = o / 4; o += nK1 * 4;
+    mp.oK4 = o / 4; o += nK4 * 4;
+    mp.oAZ = o / 4; o += nA * 4;
+    mp.oAT = o / 4; o += nA * 4;
+    pl.pad_ = (int)(o - base.oPlan);                           // floats behind the plan record this kernel needs
+    *out = mp;
+    return 0;
+}
+
+static size_t mono_ws_bytes(const MonoPlan& mp) {
+    return (size_t)(mp.pp.oPlan + mp.pp.pad_) * sizeof(float);
 }
 
 static size_t plan_ws_bytes(const DevPlan& pl) {
@@ -1933,6 +1994,8 @@ size_t nocf_rollout_workspace_bytes(int32_t d, int32_t m, int32_t nTh, int64_t n
     if (n > 0 && make_group_plan(pl, 1, NOCF_PROB_QUADCOPTER, n, &gp) == 0) b = std::max(b, group_ws_bytes(gp));   // LDS-lightest view; sizes of the exchange area do not depend on the problem
     SlabPlan sp;
     if (n > 0 && make_slab_plan(pl, 1, std::min<long>(n, 1024), &sp) == 0) b = std::max(b, slab_ws_bytes(sp));
+    MonoPlan mpl;
+    if (make_mono_plan(pl, 1, &mpl) == 0) b = std::max(b, mono_ws_bytes(mpl));
     return b;
 }
 
@@ -2015,11 +2078,45 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) use_group = false;
         else if ((long)gp.ngroups * gp.G > 2L * cus) use_group = false;
     }
+    // one-CU weight-stationary kernel (nocf_mono.inc): two-layer networks of up to 128 hidden units whose shape has an
+    // instantiation (singlequad): no weight stream, no inter-workgroup traffic; also with intermediates
+    MonoPlan mpl;
+    const bool use_mono = !s_all && env_int("NOCF_MONO", 1) != 0 && !(env_int("NOCF_GROUP", 0) != 0) &&
+                          make_mono_plan(pl, pb.nAgents, &mpl) == 0 && workspace_bytes >= mono_ws_bytes(mpl);
+    if (use_mono) {
+        mpl.pp.cb = phi->cb;
+        DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
+        hipLaunchKernelGGL(mono_pack_kernel, dim3(64), dim3(256), 0, st, mpl, P, ws);
+        const size_t ldsBytes = (size_t)mpl.pp.ldsFloats * 4;
+        const void* fk = nullptr;
+#define NOCF_MONO_PICK(M_, D_) if (mpl.KBM == M_ && mpl.KBD == D_) fk = reinterpret_cast<const void*>(rollout_mono_kernel<M_, D_>);
+        MONO_SHAPES(NOCF_MONO_PICK)
+#undef NOCF_MONO_PICK
+        e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
+        if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] mono kernel: %d hidden / %d input k-blocks, LDS %zu B/workgroup\n", mpl.KBM, mpl.KBD, ldsBytes);
+        if (g_prof_on) {
+            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+            (void)hipEventRecord(ev0, st);
+        }
+        const MonoPlan* mpp = reinterpret_cast<const MonoPlan*>(ws + mpl.pp.oPlan);
+        void* args[] = {(void*)&mpp, (void*)&pb, (void*)&ws, (void*)&ra};
+        e = hipLaunchKernel(fk, dim3((int)((n + 15) / 16)), dim3(256), args, ldsBytes, st); if (e) return (int)e;
+        g_last_kernel = "rollout_mono_kernel";
+        e = hipGetLastError();
+        if (e) return (int)e;
+        if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
+        if (cost_sums) {
+            hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
+            e = hipGetLastError();
+            if (e) return (int)e;
+        }
+        return 0;
+    }
     // weight-stationary slab kernel (nocf_slab.inc): wide two-layer networks on point-agent problems, plain rollouts of up
     // to 1024 samples (32 groups x 8 workgroups, one workgroup per CU, all resident at once)
     SlabPlan sp;
     const int slab_knob = env_int("NOCF_SLAB", 1);
-    bool use_slab = !use_group && !s_all && !zFull && slab_knob != 0 && (slab_knob >= 2 || n <= 512) && pb.kind != NOCF_PROB_QUADCOPTER &&
+    bool use_slab = !use_group && !s_all && !zFull && slab_knob != 0 && (slab_knob >= 2 || n <= 1024) && pb.kind != NOCF_PROB_QUADCOPTER &&
                     make_slab_plan(pl, pb.nAgents, n, &sp) == 0 && workspace_bytes >= slab_ws_bytes(sp);
     if (use_slab) {
         int dev = 0, cus = 0;

@@ -663,6 +663,7 @@ def test_jit_specialisation_of_an_unlisted_shape(monkeypatch, capfd):
     for jit in ("0", "1"):
         monkeypatch.setenv("NOCF_JIT", jit)
         monkeypatch.setenv("NOCF_DEBUG", "1")
+        monkeypatch.setenv("NOCF_MONO", "0")             # this shape would take the one-CU kernel, which is not shape-specialised
         net = na.Phi(nTh=2, m=m, d=d, alph=alph)
         net.load_state_dict(sd)
         net = net.to(DEV)

@@ -1,0 +1,113 @@
+"""GPU parity tests of the one-CU weight-stationary kernel (neuraloc_amd/csrc/nocf_mono.inc): two-layer networks of up to 128
+hidden units with d+1 <= 16 (singlequad).  Against the reference's stored outputs, the oracle and the per-tile kernel
+(NOCF_MONO=0), with and without intermediates.  Tolerances as in test_hip_parity.py."""
+import pytest
+import torch
+
+import neuraloc_amd as na
+from oracle import ocflow_oracle as orc
+from conftest import load_golden
+from util_hip import closed_form_normal, count_off, make_net, make_oracle, make_prob
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _table(x, net, prob, tspan, nt, stepper, alph):
+    with torch.no_grad():
+        _, csn = na.OCflow(x, net, prob, tspan, nt, stepper, alph, noMean=True)
+    return torch.cat(csn, 1).cpu()
+
+
+def _off(tab, want):
+    """per-sample costs rel 1e-3 + abs 1e-3, plus 1e-6 of the row's largest entry: cHJfin = |Phi(z(T),T) - G(z(T))| is the
+    difference of two numbers ~7e3 here, so two correct fp32 evaluations differ in it by a few ulp(7e3) ~ 1e-3..5e-3
+    (the oracle itself moves by that much when x is scaled by 1 + 1e-6; tools/mono_diff.py prints the rows)"""
+    t, w = tab.double(), want.double()
+    return (t - w).abs() > 1e-3 + 1e-3 * w.abs() + 1e-6 * w.abs().max(dim=1, keepdim=True).values
+
+
+def _flips(tab, want):
+    return int(_off(tab, want).any(dim=1).sum())
+
+
+def test_mono_kernel_is_the_default_for_singlequad(monkeypatch, capfd):
+    g = load_golden("singlequad")
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
+    monkeypatch.setenv("NOCF_DEBUG", "1")
+    _table(g.t("x").to(DEV), net, prob, [0.0, 1.0], 4, "rk4", g.meta["alph"])
+    torch.cuda.synchronize()
+    assert "mono kernel" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 17, 100, 1000, 4096])
+@pytest.mark.parametrize("stepper,tspan", [("rk4", [0.0, 1.0]), ("rk1", [0.25, 0.9])])
+def test_mono_matches_tile_kernel_and_oracle_on_singlequad(n, stepper, tspan, monkeypatch):
+    g = load_golden("singlequad")
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
+    m = g.meta
+    xi = closed_form_normal(n, m["d"], 5)
+    xi[:, 3:] = 0.0
+    x = (g.t("xInit") + m["var0"] * xi).contiguous()
+    nt = 12
+    monkeypatch.setenv("NOCF_MONO", "1")
+    mono = _table(x.to(DEV), net, prob, tspan, nt, stepper, m["alph"])
+    assert torch.equal(mono, _table(x.to(DEV), net, prob, tspan, nt, stepper, m["alph"])), "not run-to-run deterministic"
+    monkeypatch.setenv("NOCF_MONO", "0")
+    tile = _table(x.to(DEV), net, prob, tspan, nt, stepper, m["alph"])
+    assert _flips(mono, tile) <= n // 1024, f"mono vs tile kernel: {_flips(mono, tile)} samples differ"
+    keep = ~_off(mono, tile).any(dim=1)
+    for j in range(7):
+        a, b = mono[keep, j].double().mean().item(), tile[keep, j].double().mean().item()
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, f"column {j}: mean {a} vs {b}"
+    if n <= 100:
+        P, S = make_oracle(g, False)
+        want = orc.persample_table(x, P, S, tspan, nt, stepper, m["alph"])
+        assert _flips(mono, want) == 0, f"mono vs oracle: {_flips(mono, want)} samples off"
+
+
+def test_mono_intermediates_against_oracle_and_tile_kernel(monkeypatch):
+    """zFull / ctrlFull incl. the control evaluation at (z_{k+1}, t_k) and ctrlFull[...,0] == 0 (src/OCflow.py:41-55)"""
+    g = load_golden("singlequad")
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
+    m = g.meta
+    x = g.t("x")[:21].contiguous()
+    nt, d = 9, m["d"]
+    monkeypatch.setenv("NOCF_MONO", "1")
+    with torch.no_grad():
+        zF, cF = na.OCflow(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"], intermediates=True)
+    monkeypatch.setenv("NOCF_MONO", "0")
+    with torch.no_grad():
+        zT, cT = na.OCflow(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"], intermediates=True)
+        P, S = make_oracle(g, False)
+        zW, cW = orc.rollout(x, P, S, [0.0, 1.0], nt, "rk4", m["alph"], intermediates=True)
+    assert zF.shape == (21, d + 4, nt + 1) and cF.shape == (21, 4, nt + 1)
+    assert float(cF[:, :, 0].abs().max()) == 0.0
+    bad, worst = count_off(zF.cpu()[:, :d], zW[:, :d], 1e-5, 1e-4)
+    assert bad == 0, f"{bad} state entries off (worst {worst:g})"
+    bad, worst = count_off(cF.cpu(), cW, 1e-4, 1e-4 * float(cW.abs().max()) + 1e-5)
+    assert bad == 0, f"{bad} control entries off (worst {worst:g})"
+    bad, worst = count_off(zF.cpu(), zT.cpu(), 1e-4, 1e-3)
+    assert bad == 0, f"mono vs tile trajectories: {bad} entries off (worst {worst:g})"
+
+
+@pytest.mark.parametrize("m_", [24, 64, 100, 128])
+@pytest.mark.parametrize("training", [False, True])
+def test_mono_other_widths_against_oracle(m_, training):
+    """quadcopter networks of other widths (hidden units zero-padded to 32 / 64 / 128 by the images)"""
+    from test_slab_gpu import _synth_state_dict
+    alph = [5000.0, 0.0, 0.0, 0.1, 0.05, 0.02]
+    torch.manual_seed(2)
+    prob, x0, _, _ = na.initProb("singlequad", 37, 8, 0.3, alph, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    d = x0.shape[1]
+    sd = _synth_state_dict(2, m_, d, seed=m_ % 5)
+    net = na.Phi(nTh=2, m=m_, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    P = orc.PhiParams.from_state_dict(sd)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    got = _table(x0, net, prob, [0.0, 1.0], 6, "rk4", alph)
+    want = orc.persample_table(x0.cpu(), P, S, [0.0, 1.0], 6, "rk4", alph)
+    assert _flips(got, want) == 0, f"m={m_}: {_flips(got, want)} samples off"
