@@ -9,8 +9,8 @@ times the deployment like timeDeployment/timeOC.py:76-81 (nex = 1, nt steps; sam
 line, appended to `<save>/deploy_times`) plus a batch, and with --do_shock runs the reference's two softcorridor shocks
 (evalOC.py:113-122) through neuraloc_amd.shock for any problem.
 
-Differences, on purpose: --prec double is refused (the HIP path computes in fp32; the reference's double run is what the
-oracle's fp64 goldens pin); --make_vid only states that videos are out of scope; --gpu/--batch are additions."""
+--prec double runs the double-precision rollout (nocf_rollout_f64), like the reference's evalOC.py:28-31.
+Differences, on purpose: --make_vid only states that videos are out of scope; --gpu/--batch are additions."""
 import argparse
 import os
 import time
@@ -38,16 +38,14 @@ p.add_argument("--gpu", type=int, default=0, help="(addition) device index")
 def main(argv=None):
     args = p.parse_args(argv)
     args.alph = [float(item) for item in args.alph.split(",")]
-    if args.prec == "double":
-        raise SystemExit("--prec double: the MI355X path computes in fp32 (fp64 entry points are not built); "
-                         "run the reference for a double-precision evaluation")
+    prec = torch.float64 if args.prec == "double" else torch.float32          # evalOC.py:28-31
     os.makedirs(os.path.join(args.save, "figs"), exist_ok=True)
     print(args)
     dev = f"cuda:{args.gpu}"
     print(" ")
     print("loading model: {:}".format(args.resume))
     print(" ")
-    net, prob, x0, _, xInit, a = load_checkpoint(args.resume, device=dev, n_train=args.batch, n_val=args.batch)
+    net, prob, x0, _, xInit, a = load_checkpoint(args.resume, device=dev, n_train=args.batch, n_val=args.batch, dtype=prec)
     prob.eval()
     net.eval()
     alph = net.alph
@@ -95,8 +93,8 @@ def main(argv=None):
         if args.do_shock:
             d = xInit.shape[1]
             for tag, vals in (("shock", [-0.2, -0.7, -0.0, -0.6]), ("majorshock", [-1.4, -1.0, -5.2, -2.8])):       # evalOC.py:115-120
-                shock = torch.zeros(1, d, device=xInit.device)
-                shock[0, : min(4, d)] = torch.tensor(vals)[: min(4, d)]
+                shock = torch.zeros(1, d, device=xInit.device, dtype=xInit.dtype)
+                shock[0, : min(4, d)] = torch.tensor(vals, dtype=xInit.dtype)[: min(4, d)]
                 res = shock_rollout(xInit, net, prob, nt, 0.1, shock)
                 np.savez(os.path.join(args.save, "figs", f"{strTitle}_{tag}.npz"), traj=res["traj"].cpu().numpy(), ctrl=res["ctrl"].cpu().numpy())
                 print("%s at t=0.1: nShock=%d, final state error %.4e" %

@@ -219,6 +219,40 @@ int nocf_phi_forward_f32(const NocfPhi* phi, const float* s, int64_t n, float* v
 int nocf_prob_eval_f32(const NocfProb* prob, int32_t d, const float* x, const float* p, int64_t n,
                        float* lhqw, float* gradpH, float* ctrls, void* stream);
 
+/*
+ * Double precision -- the reference's `--prec double` (trainOC.py:76-79,96; evalOC.py:19,28-31): net, problem and states go
+ * through .to(torch.float64) and the same OCflow (src/OCflow.py:7-95) runs.  Same arguments and layouts as nocf_rollout_f32 with
+ * every buffer in double (alph: host [6] doubles; cost_sums: 7 column sums then n, as doubles).  Evaluation only (the adjoint is
+ * fp32).  c.bias is read on the device (cb_dev is required).  workspace: nocf_workspace_bytes_f64(d, m, nTh) bytes.
+ */
+typedef struct NocfPhi64 {
+    int32_t d, m, nTh, r;
+    const double* K0;    /* device [m, d+1]      */
+    const double* b0;    /* device [m]           */
+    const double* K;     /* device [nTh-1, m, m] */
+    const double* b;     /* device [nTh-1, m]    */
+    const double* w;     /* device [m]           */
+    const double* A;     /* device [r, d+1]      */
+    const double* cw;    /* device [d+1]         */
+    const double* cb_dev;/* device [1]           */
+} NocfPhi64;
+
+typedef struct NocfProb64 {
+    int32_t kind, obstacle, n_agents, training;
+    double r, alph_Q, alph_W, mass, grav;
+    const double* xtarget; /* device [d] */
+} NocfProb64;
+
+size_t nocf_workspace_bytes_f64(int32_t d, int32_t m, int32_t nTh);
+
+int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob,
+                     const double* x, int64_t n,
+                     double t0, double t1, int32_t nt, int32_t stepper,
+                     const double* alph,
+                     double* z_out, double* persample, double* cost_sums,
+                     double* zFull, double* ctrlFull,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement hooks (bench.py): between begin and end every nocf_rollout_f32 call records a pair
  * of HIP events on its launch stream immediately around the rollout kernel; end synchronises on
  * them and returns the summed kernel time and the number of launches.  Not thread-safe. */

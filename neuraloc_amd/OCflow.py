@@ -24,8 +24,46 @@ def ocG(z, xtarget):
     return z[:, 0:d] - xtarget
 
 
+def _launch64(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
+    """the double-precision rollout (nocf_rollout_f64): the reference's --prec double (evalOC.py:19,28-31)"""
+    x = _lib.require_device_f64(x, "x")
+    if x.dim() != 2:
+        raise ValueError("x must be nex-by-d")
+    n, d = x.shape
+    if d != Phi.d:
+        raise ValueError(f"x has d={d} but Phi was built for d={Phi.d}")
+    if int(nt) < 1:
+        raise ValueError("nt must be >= 1")
+    if stepper not in _STEPPERS:
+        raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
+    if len(alph) < 6:
+        raise ValueError("alph needs 6 entries")
+    Phi._guard_no_autograd(x, "OCflow (double precision: evaluation only, the adjoint is fp32)")
+    phi_st, keep1, ws = Phi._c_struct64()
+    prob_st, keep2 = prob._c_struct64(x.device)
+    dev = x.device
+    persample = torch.empty(n, 7, dtype=torch.float64, device=dev)
+    sums = torch.empty(8, dtype=torch.float64, device=dev)
+    zFull = ctrlFull = None
+    if intermediates:
+        p32, _k = prob._c_struct(dev)
+        cdim = _lib.lib().nocf_ctrl_dim(C.byref(p32), d)
+        zFull = torch.empty(nt + 1, n, d + 4, dtype=torch.float64, device=dev)
+        ctrlFull = torch.empty(nt + 1, n, cdim, dtype=torch.float64, device=dev)
+    alph_c = (C.c_double * 6)(*[float(a) for a in alph[:6]])
+    with torch.cuda.device(dev):
+        rc = _lib.lib().nocf_rollout_f64(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+                                         float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
+                                         None, _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(zFull), _lib.ptr(ctrlFull),
+                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "nocf_rollout_f64")
+    return persample, sums, zFull, ctrlFull
+
+
 def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
     """run the HIP rollout; returns (persample [n,7], sums [8], zFull_tm, ctrlFull_tm)"""
+    if isinstance(x, torch.Tensor) and x.dtype == torch.float64:
+        return _launch64(x, Phi, prob, tspan, nt, stepper, alph, intermediates)
     x = _lib.require_device_f32(x, "x")
     if x.dim() != 2:
         raise ValueError("x must be nex-by-d")
@@ -68,7 +106,7 @@ def costs_from_sums(sums, alph):
     cs order is [L, G, HJt, HJfin, HJgrad, Q, W]; G is un-weighted (src/OCflow.py:80-90).
     On the device this is one tiny launch (nocf_cost_means_f32); host tensors (the gloo tests' injected sums) take
     the same formula in torch."""
-    if sums.is_cuda:
+    if sums.is_cuda and sums.dtype == torch.float32:
         out = torch.empty(8, dtype=torch.float32, device=sums.device)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         with torch.cuda.device(sums.device):
@@ -84,7 +122,8 @@ def costs_from_sums(sums, alph):
 def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0],
            intermediates=False, noMean=False):
     """
-    :param x:       nex-by-d tensor on the MI355X, fp32
+    :param x:       nex-by-d tensor on the MI355X, fp32 (or float64 together with Phi and prob: the reference's --prec double,
+                    evaluation only)
     :param Phi:     neuraloc_amd.Phi
     :param prob:    neuraloc_amd problem object (Cross2D / SwarmTraj / Quadcopter)
     :param tspan:   [t0, t1]
@@ -96,12 +135,16 @@ def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0
                     like the reference: src/OCflow.py:66-76)
     :return: (Jc, cs)  or  (zFull, ctrlFull)
     """
-    if (torch.is_grad_enabled() and not intermediates and not noMean
+    if (torch.is_grad_enabled() and not intermediates and not noMean and x.dtype != torch.float64
             and (x.requires_grad or any(p.requires_grad for p in Phi.parameters()))):
         from .train import ocflow_train                 # trainOC.py:172-173: Jc.backward() -> hand-written adjoint
         if int(nt) < 1:
             raise ValueError("nt must be >= 1")
         return ocflow_train(x, Phi, prob, tspan, nt, stepper, alph)
+    if (x.dtype == torch.float64 and torch.is_grad_enabled()
+            and (x.requires_grad or any(p.requires_grad for p in Phi.parameters()))):
+        raise NotImplementedError("OCflow in double precision is evaluation only (the adjoint kernels are fp32): call it under "
+                                  "torch.no_grad(); train in single precision (trainOC.py's default)")
     persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates and not noMean)
     if noMean:
         cs = [persample[:, i:i + 1] for i in range(7)]

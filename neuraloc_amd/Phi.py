@@ -102,6 +102,40 @@ class Phi(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         return st, keep, self._ws
 
+    def _c_struct64(self):
+        """(NocfPhi64, keep-alive list, workspace) for a double-precision rollout: the module after .to(torch.float64)"""
+        dev = self.A.device
+        lay = self.N.layers
+        keep = []
+
+        def dv(t, name):
+            t = _lib.require_device_f64(t.detach(), name)
+            keep.append(t)
+            return t.data_ptr()
+
+        if self.nTh == 2:
+            Kst, bst = lay[1].weight, lay[1].bias
+        else:
+            Kst = torch.stack([lay[i].weight.detach() for i in range(1, self.nTh)])
+            bst = torch.stack([lay[i].bias.detach() for i in range(1, self.nTh)])
+        st = _lib.NocfPhi64()
+        st.d, st.m, st.nTh, st.r = self.d, self.m, self.nTh, self.A.shape[0]
+        st.K0 = dv(lay[0].weight, "N.layers.0.weight")
+        st.b0 = dv(lay[0].bias, "N.layers.0.bias")
+        st.K = dv(Kst, "N.layers[1:].weight")
+        st.b = dv(bst, "N.layers[1:].bias")
+        st.w = dv(self.w.weight, "w.weight")
+        st.A = dv(self.A, "A")
+        st.cw = dv(self.c.weight, "c.weight")
+        st.cb_dev = dv(self.c.bias, "c.bias")
+        nbytes = _lib.lib().nocf_workspace_bytes_f64(self.d, self.m, self.nTh)
+        if nbytes == 0:
+            raise RuntimeError("nocf_workspace_bytes_f64: unsupported (d, m, nTh)")
+        ws = getattr(self, "_ws64", None)
+        if ws is None or ws.device != dev or ws.numel() < nbytes:
+            ws = self._ws64 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return st, keep, ws
+
     def _guard_no_autograd(self, x, what):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(

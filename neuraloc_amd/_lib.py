@@ -32,6 +32,18 @@ class NocfProb(C.Structure):
                 ("mass", C.c_double), ("grav", C.c_double), ("xtarget", C.c_void_p)]
 
 
+class NocfPhi64(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("nTh", C.c_int32), ("r", C.c_int32),
+                ("K0", C.c_void_p), ("b0", C.c_void_p), ("K", C.c_void_p), ("b", C.c_void_p),
+                ("w", C.c_void_p), ("A", C.c_void_p), ("cw", C.c_void_p), ("cb_dev", C.c_void_p)]
+
+
+class NocfProb64(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("obstacle", C.c_int32), ("n_agents", C.c_int32), ("training", C.c_int32),
+                ("r", C.c_double), ("alph_Q", C.c_double), ("alph_W", C.c_double),
+                ("mass", C.c_double), ("grav", C.c_double), ("xtarget", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -133,6 +145,12 @@ def _bind(L):
     L.nocf_profile_begin.restype = C.c_int
     L.nocf_profile_end.restype = C.c_int
     L.nocf_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.nocf_workspace_bytes_f64.restype = C.c_size_t
+    L.nocf_workspace_bytes_f64.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.nocf_rollout_f64.restype = C.c_int
+    L.nocf_rollout_f64.argtypes = [C.POINTER(NocfPhi64), C.POINTER(NocfProb64), C.c_void_p, C.c_int64,
+                                   C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.nocf_debug_set_stamp_buffer.restype = C.c_int
     L.nocf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     L.nocf_selftest_mfma.restype = C.c_int
@@ -156,6 +174,19 @@ def require_device_f32(t, name):
                            "there is no CPU fallback")
     if t.dtype != torch.float32:
         raise RuntimeError(f"{name} has dtype {t.dtype}: the HIP path computes in fp32 only")
+    return t.contiguous()
+
+
+def require_device_f64(t, name):
+    """double precision (the reference's --prec double): every tensor of the call must be float64 on the MI355X"""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the OCflow hot path runs only on an MI355X (ROCm 'cuda' device); "
+                           "there is no CPU fallback")
+    if t.dtype != torch.float64:
+        raise RuntimeError(f"{name} has dtype {t.dtype} in a double-precision call: convert the network, the problem and the "
+                           "states together (net.to(torch.float64), initProb(..., cvt) with a float64 cvt), like the reference's --prec double")
     return t.contiguous()
 
 

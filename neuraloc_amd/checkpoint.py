@@ -26,18 +26,19 @@ def load_file(path, trusted=False):
                            "trusted=True or set NOCF_TRUST_CHECKPOINTS=1") from exc
 
 
-def load_checkpoint(path, device="cuda:0", n_train=None, n_val=None, var0=None):
-    """-> (net, prob, x0, x0v, xInit, args); `args` is the pickled Namespace (see load_file)"""
+def load_checkpoint(path, device="cuda:0", n_train=None, n_val=None, var0=None, dtype=torch.float32):
+    """-> (net, prob, x0, x0v, xInit, args); `args` is the pickled Namespace (see load_file).  dtype=torch.float64 is the
+    reference's --prec double (evalOC.py:28-31: `cvt` and net.to(prec))"""
     ck = load_file(path)
     a = ck["args"]
     alph = [float(v) for v in a.alph]
     dev = torch.device(device)
-    cvt = lambda t: t.to(torch.float32).to(dev)           # noqa: E731
+    cvt = lambda t: t.to(dtype).to(dev)                   # noqa: E731
     prob, x0, x0v, xInit = initProb(a.data, n_train or getattr(a, "n_train", 1024), n_val or getattr(a, "n_train", 1024),
                                     var0=var0 if var0 is not None else getattr(a, "var0", 1.0), alph=alph, cvt=cvt)
     net = Phi(nTh=a.nTh, m=a.m, d=x0.shape[1], alph=alph)
     net.load_state_dict(ck["state_dict"])
-    return net.to(torch.float32).to(dev), prob, x0, x0v, xInit, a
+    return net.to(dtype).to(dev), prob, x0, x0v, xInit, a
 
 
 def save_checkpoint(path, net, args):

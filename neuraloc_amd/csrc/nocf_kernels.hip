@@ -1595,6 +1595,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 #include "nocf_group.inc"
 #include "nocf_slab.inc"
 #include "nocf_mono.inc"
+#include "nocf_f64.inc"
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
 #include "nocf_lane_bwd.inc"
@@ -2355,6 +2356,63 @@ int nocf_selftest_mfma(const float* a, const float* b, int32_t K, float* out, vo
     if (!a || !b || !out) return NOCF_E_NULL;
     hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, K, out);
     return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// double precision (nocf_f64.inc)
+// ------------------------------------------------------------------------------------------
+size_t nocf_workspace_bytes_f64(int32_t d, int32_t m, int32_t nTh) {
+    if (d < 1 || m < 1 || nTh < 2) return 0;
+    return f64_ws_doubles(d, m, nTh) * sizeof(double);
+}
+
+int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob, const double* x, int64_t n,
+                     double t0, double t1, int32_t nt, int32_t stepper, const double* alph,
+                     double* z_out, double* persample, double* cost_sums, double* zFull, double* ctrlFull,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!phi || !prob) return NOCF_E_NULL;
+    if (!phi->K0 || !phi->b0 || !phi->K || !phi->b || !phi->w || !phi->A || !phi->cw || !phi->cb_dev) return NOCF_E_NULL;
+    if (!x || !alph || !workspace || !prob->xtarget) return NOCF_E_NULL;
+    if (n < 1 || nt < 1 || phi->d < 1 || phi->m < 1 || phi->nTh < 2 || phi->r < 1 || phi->r > 16) return NOCF_E_SHAPE;
+    if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
+    if ((zFull != nullptr) != (ctrlFull != nullptr)) return NOCF_E_NULL;
+    if (cost_sums && !persample) return NOCF_E_NULL;
+    NocfProb p32;                                    // the same checks as the fp32 entry (kind / obstacle / agent count)
+    p32.kind = prob->kind; p32.obstacle = prob->obstacle; p32.n_agents = prob->n_agents; p32.training = prob->training;
+    p32.r = prob->r; p32.alph_Q = prob->alph_Q; p32.alph_W = prob->alph_W; p32.mass = prob->mass; p32.grav = prob->grav; p32.xtarget = nullptr;
+    DevProb pb32;
+    int rc = fill_prob(&p32, phi->d, &pb32);
+    if (rc) return rc;
+    F64Prob pb{pb32.kind, pb32.obstacle, pb32.nAgents, pb32.training, pb32.agentDim, prob->r, prob->alph_Q, prob->alph_W, prob->mass, prob->grav, prob->xtarget};
+    if (workspace_bytes < nocf_workspace_bytes_f64(phi->d, phi->m, phi->nTh)) return NOCF_E_WORKSPACE;
+    // samples per workgroup: 4 when the batch still fills the chip that way, fewer for small batches or tight LDS
+    F64Plan pl;
+    int T = 0;
+    const int pref[3] = {n >= 1024 ? 4 : (n >= 512 ? 2 : 1), 2, 1};
+    for (int q = 0; q < 3 && !T; ++q) if ((q == 0 || pref[q] < pref[0]) && make_f64_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, pref[q], &pl) == 0) T = pref[q];
+    if (!T) return NOCF_E_LDS;
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+    F64Phi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev, phi->d, phi->m, phi->nTh, phi->r};
+    hipLaunchKernelGGL(f64_pack_kernel, dim3(512), dim3(256), 0, st, pl, P, ws);
+    F64Args ra;
+    ra.x = x; ra.n = n; ra.t0 = t0; ra.t1 = t1; ra.h = (t1 - t0) / nt; ra.nt = nt; ra.stepper = stepper; ra.a0 = alph[0];
+    ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull;
+    ra.cdim = nocf_ctrl_dim(&p32, phi->d);
+    const size_t ldsBytes = (size_t)pl.ldsDoubles * 8;
+    const void* fk = T == 4 ? reinterpret_cast<const void*>(rollout_f64_kernel<4>)
+                   : T == 2 ? reinterpret_cast<const void*>(rollout_f64_kernel<2>) : reinterpret_cast<const void*>(rollout_f64_kernel<1>);
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e) return (int)e;
+    if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] f64 kernel: %d sample(s) per workgroup, LDS %zu B\n", T, ldsBytes);
+    const double* wsc = ws;
+    void* args[] = {(void*)&pl, (void*)&P, (void*)&pb, (void*)&wsc, (void*)&ra};
+    e = hipLaunchKernel(fk, dim3((unsigned)((n + T - 1) / T)), dim3(256), args, ldsBytes, st);
+    if (e) return (int)e;
+    g_last_kernel = "rollout_f64_kernel";
+    if (cost_sums) hipLaunchKernelGGL(f64_cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums);
+    e = hipGetLastError();
+    return (int)e;
 }
 
 }  // extern "C"

@@ -41,6 +41,19 @@ class _ProblemBase:
         st.xtarget = xt.data_ptr()
         return st, [xt]
 
+    def _c_struct64(self, device):
+        """the same attributes for the double-precision entry point (xtarget as float64)"""
+        if self.obstacle not in _lib.OBS_CODES:
+            raise ValueError(f"obstacle {self.obstacle!r} is not one the reference implements")
+        xt = self.xtarget.detach().to(device=device, dtype=torch.float64).contiguous()
+        st = _lib.NocfProb64()
+        st.kind, st.obstacle = self.KIND, _lib.OBS_CODES[self.obstacle]
+        st.n_agents, st.training = self.nAgents, int(bool(self.training))
+        st.r, st.alph_Q, st.alph_W = float(self.r), float(self.alph_Q), float(self.alph_W)
+        st.mass, st.grav = float(getattr(self, "mass", 1.0)), float(getattr(self, "grav", 9.81))
+        st.xtarget = xt.data_ptr()
+        return st, [xt]
+
     def _eval(self, x, p, want):
         x = _lib.require_device_f32(x, "x")
         p = _lib.require_device_f32(p, "p")

@@ -73,8 +73,17 @@ def test_evalOC_on_a_reference_checkpoint(tmp_path, capsys):
     assert z["zFull"].shape == (1, m["d"] + 4, int(g["xinit_eval/nt"]) + 1) and z["ctrlFull"].shape[1] == m["d"]
     assert os.path.exists(os.path.join(save, "figs", "eval_softcorridor_nn_shock.npz"))
     assert "majorshock at t=0.1" in text
-    with pytest.raises(SystemExit):
-        evalOC.main(["--resume", ck, "--prec", "double"])
+    # --prec double (evalOC.py:19,28-31): the same evaluation through the double-precision rollout, incl. the shocked rollouts
+    save64 = os.path.join(str(tmp_path), "eval64")
+    out64 = evalOC.main(["--resume", ck, "--nt", str(int(g["xinit_eval/nt"])), "--save", save64, "--do_shock", "--batch", "16",
+                         "--prec", "double"])
+    assert abs(out64["Jc"] - want_J) <= 1e-4 * abs(want_J)               # the fp32 known answer, to fp32 accuracy
+    for got, want in zip(out64["cs"], want_cs):
+        assert abs(got - want) <= 1e-4 * abs(want) + 1e-6
+    z64 = np.load(os.path.join(save64, "figs", "eval_softcorridor_nn.npz"))
+    assert z64["zFull"].dtype == np.float64 and z64["zFull"].shape == z["zFull"].shape
+    assert float(np.abs(z64["zFull"][:, :m["d"]] - z["zFull"][:, :m["d"]]).max()) <= 1e-3
+    assert os.path.exists(os.path.join(save64, "figs", "eval_softcorridor_nn_majorshock.npz"))
 
 
 def test_training_path_validates_its_inputs_and_parameter_versions():
