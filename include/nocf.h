@@ -199,6 +199,14 @@ int nocf_rollout_bwd_small_f32(const NocfPhi* phi, const NocfProb* prob, int64_t
 int nocf_contract_f32(const float* A, const float* B, int64_t K, int32_t m, int32_t n, float* C, int32_t accumulate,
                       float* scratch, size_t scratch_floats, void* stream);
 
+/*
+ * out[n] (+)= column sums of X [K, n]: the bias, w and c.weight gradients are the sums of the adjoint's rows over every sample and
+ * evaluation (torch autograd's sum-to-size in the backward of trainOC.py:173).  Two launches, fixed order (deterministic), reads
+ * X once at HBM speed.  scratch device [scratch_floats]: n floats per row slice (up to 2048 slices of >= 128 rows).
+ */
+int nocf_colsum_f32(const float* X, int64_t K, int32_t n, float* out, int32_t accumulate,
+                    float* scratch, size_t scratch_floats, void* stream);
+
 /* Phi.getGrad -- replaces src/Phi.py:99-138.  s: device [n, d+1] -> grad: device [n, d+1] */
 int nocf_phi_grad_f32(const NocfPhi* phi, const float* s, int64_t n, float* grad,
                       void* workspace, size_t workspace_bytes, void* stream);

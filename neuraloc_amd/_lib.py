@@ -145,6 +145,8 @@ def _bind(L):
     L.nocf_profile_begin.restype = C.c_int
     L.nocf_profile_end.restype = C.c_int
     L.nocf_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.nocf_colsum_f32.restype = C.c_int
+    L.nocf_colsum_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
     L.nocf_workspace_bytes_f64.restype = C.c_size_t
     L.nocf_workspace_bytes_f64.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.nocf_rollout_f64.restype = C.c_int

@@ -1585,6 +1585,31 @@ __global__ void __launch_bounds__(256) contract_reduce_kernel(const float* __res
     }
 }
 
+// column sums of a row stream X [K, n] (the bias / w / c gradients: sums over every sample and evaluation of the adjoint's rows):
+// thread = column (consecutive threads on consecutive addresses), workgroup = a slice of rows, 8 rows in flight per thread;
+// stage 2 adds the slices' partials in a fixed order
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ X, long K, int n, long rows_per_block, float* __restrict__ part) {
+    const int col = blockIdx.y * 256 + threadIdx.x;
+    if (col >= n) return;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = (r0 + rows_per_block < K) ? r0 + rows_per_block : K;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    long r = r0;
+    for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += X[(r + u) * n + col];
+    }
+    for (; r < r1; ++r) a[0] += X[r * n + col];
+    part[(long)blockIdx.x * n + col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+__global__ void __launch_bounds__(256) colsum_reduce_kernel(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out, int accumulate) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(long)b * n + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
 __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* __restrict__ b, int K, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1944,6 +1969,22 @@ int nocf_contract_f32(const float* A, const float* B, int64_t K, int32_t m, int3
     return (int)hipGetLastError();
 }
 
+int nocf_colsum_f32(const float* X, int64_t K, int32_t n, float* out, int32_t accumulate, float* scratch, size_t scratch_floats, void* stream) {
+    if (!X || !out || !scratch) return NOCF_E_NULL;
+    if (K < 1 || n < 1) return NOCF_E_SHAPE;
+    const int cb = (n + 255) / 256;
+    long nblocks = (K + 127) / 128;                       // >= 128 rows per workgroup
+    if (nblocks > 2048 / cb) nblocks = 2048 / cb;
+    if ((size_t)nblocks * n > scratch_floats) nblocks = (long)(scratch_floats / (size_t)n);
+    if (nblocks < 1) return NOCF_E_WORKSPACE;
+    const long rpb = (K + nblocks - 1) / nblocks;
+    nblocks = (K + rpb - 1) / rpb;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((int)nblocks, cb), dim3(256), 0, st, X, (long)K, n, rpb, scratch);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cb), dim3(256), 0, st, scratch, (int)nblocks, n, out, accumulate);
+    return (int)hipGetLastError();
+}
+
 int nocf_debug_set_timeline_buffer(void* device_buf) {
 #ifdef NOCF_STAMPS
     unsigned long long* p = (unsigned long long*)device_buf;
@@ -2117,7 +2158,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     // to 1024 samples (32 groups x 8 workgroups, one workgroup per CU, all resident at once)
     SlabPlan sp;
     const int slab_knob = env_int("NOCF_SLAB", 1);
-    bool use_slab = !use_group && !s_all && !zFull && slab_knob != 0 && (slab_knob >= 2 || n <= 1024) && pb.kind != NOCF_PROB_QUADCOPTER &&
+    bool use_slab = !use_group && !zFull && slab_knob != 0 && (slab_knob >= 2 || n <= 1024) && pb.kind != NOCF_PROB_QUADCOPTER &&
                     make_slab_plan(pl, pb.nAgents, n, &sp) == 0 && workspace_bytes >= slab_ws_bytes(sp);
     if (use_slab) {
         int dev = 0, cus = 0;

@@ -51,6 +51,20 @@ def _contract(X, Y, out=None):
     return out
 
 
+def _colsum(X):
+    """column sums of a row stream X [K, n] -> [n] (nocf_colsum_f32: two launches, fixed order, one pass over X)"""
+    dev = X.device
+    sc = _SCRATCH.get(dev)
+    if sc is None:
+        sc = _SCRATCH[dev] = torch.empty(1024 * 4096, device=dev)
+    out = torch.empty(X.shape[1], device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().nocf_colsum_f32(_lib.ptr(X), X.shape[0], X.shape[1], _lib.ptr(out), 0, _lib.ptr(sc), sc.numel(),
+                                        _lib.stream_ptr(dev))
+    _lib.check(rc, "nocf_colsum_f32")
+    return out
+
+
 class _OCflowTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
@@ -165,13 +179,12 @@ class _OCflowTrain(torch.autograd.Function):
                                                  _lib.ptr(PHIb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_bwd_f32")
         sT = Sx[(nt * nstage + 1) * n:]                                     # s at the final time (value rows)
-        ones = torch.ones(rows, 1, device=dev)                            # column sums are contractions with a column of ones
-        grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": _contract(ones, Ob).reshape(-1)}
+        grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": _colsum(Ob)}
         for i in range(1, L + 1):
             grads[f"N.layers.{i}.weight"] = _contract(Qb[i - 1], U0[i - 1], _contract(V[i - 1], Ab[i - 1]))
-            grads[f"N.layers.{i}.bias"] = _contract(ones, Qb[i - 1]).reshape(-1)
-        grads["w.weight"] = _contract(ones, Wb)
-        grads["c.weight"] = (_contract(ones, Gb).reshape(-1) + PHIb @ sT).reshape(1, -1)
+            grads[f"N.layers.{i}.bias"] = _colsum(Qb[i - 1])
+        grads["w.weight"] = _colsum(Wb).reshape(1, -1)
+        grads["c.weight"] = (_colsum(Gb) + PHIb @ sT).reshape(1, -1)
         grads["c.bias"] = PHIb.sum().reshape(1)
         dM = _contract(Gb, Sx) + 0.5 * (sT * PHIb[:, None]).t() @ sT
         grads["A"] = net.A.detach() @ (dM + dM.t())
