@@ -1,30 +1,31 @@
 #!/bin/bash
-# GPU box: the round-2 evidence under gpurun_out/r2 (copied to profiles/r2 afterwards)
+# GPU box: the round-2 evidence under gpurun_out/r2 (copied to profiles/r2 afterwards).  Every step under its own timeout.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 O=gpurun_out/r2
 mkdir -p $O
-# 1. kernel-trace stats of the default bench command (n = 1024, tile kernel) and of the 512-row proxy (slab kernel)
-rocprofv3 --kernel-trace --stats -d $O/prof_n1024 -o n1024 --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_n1024.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/prof_n512 -o n512 --output-format csv -- python3 bench.py --n 512 --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_n512.log 2>&1
-find $O/prof_n1024 -name "*kernel_stats.csv" -exec cp {} $O/01_n1024_kernel_stats.csv \;
+T="timeout 600"
+# 1. kernel-trace stats of the default bench command (n = 1024: slab kernel), of the 512-row proxy and of singlequad (mono kernel)
+$T rocprofv3 --kernel-trace --stats -d $O/prof_n1024 -o n1024 --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_n1024.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $O/prof_n512 -o n512 --output-format csv -- python3 bench.py --n 512 --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_n512.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $O/prof_sq -o sq --output-format csv -- python3 bench.py --workload singlequad --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_sq.log 2>&1
+find $O/prof_n1024 -name "*kernel_stats.csv" -exec cp {} $O/01_n1024_slab_kernel_stats.csv \;
 find $O/prof_n512 -name "*kernel_stats.csv" -exec cp {} $O/01_n512_slab_kernel_stats.csv \;
-# 2. PMC passes (separate runs, counters only)
-for n in 1024 512; do
-  rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$n -o f --output-format csv -- python3 bench.py --n $n --steps 4 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$n.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$n -o w --output-format csv -- python3 bench.py --n $n --steps 4 --warmup 1 --no-cpu-baseline > $O/pmc_write_$n.log 2>&1
-done
-python tools/parse_pmc.py $O/pmc_fetch_1024 $O/pmc_write_1024 swarm50 $O/02_hbm_traffic_n1024_tile.json "rollout_kernel" "rollout_kernel<shape-specialised>" 1024 "profiles/r2/02_hbm_traffic_n1024_tile.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes" > $O/02_parse_1024.log 2>&1
-python tools/parse_pmc.py $O/pmc_fetch_512 $O/pmc_write_512 swarm50 $O/02_hbm_traffic_n512_slab.json "rollout_slab_kernel" "rollout_slab_kernel" 512 "profiles/r2/02_hbm_traffic_n512_slab.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes" > $O/02_parse_512.log 2>&1
+find $O/prof_sq -name "*kernel_stats.csv" -exec cp {} $O/01_singlequad_mono_kernel_stats.csv \;
+# 2. PMC passes (separate runs, counters only): HBM traffic of the n = 1024 launch (slab kernel)
+$T rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_1024 -o f --output-format csv -- python3 bench.py --n 1024 --steps 4 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_1024.log 2>&1
+$T rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_1024 -o w --output-format csv -- python3 bench.py --n 1024 --steps 4 --warmup 1 --no-cpu-baseline > $O/pmc_write_1024.log 2>&1
+python tools/parse_pmc.py $O/pmc_fetch_1024 $O/pmc_write_1024 swarm50 $O/02_hbm_traffic_n1024_slab.json "rollout_slab_kernel" "rollout_slab_kernel" 1024 "profiles/r2/02_hbm_traffic_n1024_slab.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes" > $O/02_parse_1024.log 2>&1
 # 3. the default bench line and the strong-scaling proxy table
-python bench.py > $O/03_bench_default.json 2> $O/03_bench_default.err
+cp $O/02_hbm_traffic_n1024_slab.json profiles/hbm_traffic_swarm50.json 2>/dev/null
+$T python bench.py > $O/03_bench_default.json 2> $O/03_bench_default.err
 : > $O/04_proxy_table.jsonl
-for n in 1024 512 256 128; do python bench.py --n $n --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/04_proxy_table.jsonl; done
-NOCF_SLAB=0 python bench.py --n 128 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/04_proxy_table.jsonl
-NOCF_SLAB=2 python bench.py --n 1024 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/04_proxy_table.jsonl
+for n in 1024 512 256 128; do timeout 300 python bench.py --n $n --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/04_proxy_table.jsonl; done
+NOCF_SLAB=0 timeout 300 python bench.py --n 1024 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/04_proxy_table.jsonl
+NOCF_SLAB=0 timeout 300 python bench.py --n 128 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/04_proxy_table.jsonl
 python - <<'PY' > gpurun_out/r2/04_proxy_table.txt
 import json
-print("strong-scaling proxy on ONE MI355X: the per-rank batch of swarm50 n=1024 at 1/2/4/8 GPUs (bench.py --n ROWS), nt=80")
+print("strong-scaling proxy on ONE MI355X: the per-rank batch of swarm50 n=1024 at 1/2/4/8 GPUs (bench.py --n ROWS), nt=80; last two lines: the tile kernel (NOCF_SLAB=0)")
 for line in open("gpurun_out/r2/04_proxy_table.jsonl"):
     try:
         j = json.loads(line)
@@ -33,10 +34,16 @@ for line in open("gpurun_out/r2/04_proxy_table.jsonl"):
         print("ERR", line[:200])
 PY
 cat $O/04_proxy_table.txt
-# 4. the other workloads, the shock sweep, the slab stamps
-bash tools/all_workloads.sh > $O/05_all_workloads.txt 2>&1
-python bench.py --workload singlequad-shock --steps 5 --warmup 1 2>/dev/null | tail -1 > $O/06_shock_sweep.json
-for n in 512 1024; do NOCF_SLAB=2 NOCF_LIB_PATH=neuraloc_amd/csrc/libnocf_stamps.so python tools/slab_stamps.py $n 2>&1 | grep -v amdgpu.ids; done > $O/07_slab_stamps.txt
-python tools/time_train.py > $O/08_train_times.txt 2>&1
-rm -rf $O/prof_n1024 $O/prof_n512 $O/pmc_fetch_* $O/pmc_write_*
+# 4. the other workloads, the shock sweep, stamps / timelines, training, double precision
+timeout 900 bash tools/all_workloads.sh > $O/05_all_workloads.txt 2>&1
+for mono in 1 0; do NOCF_MONO=$mono timeout 300 python bench.py --workload singlequad-shock --steps 5 --warmup 1 2>/dev/null | tail -1; done > $O/06_shock_sweep.jsonl
+for n in 512 1024; do NOCF_SLAB=2 NOCF_LIB_PATH=neuraloc_amd/csrc/libnocf_stamps.so timeout 300 python tools/slab_timeline.py $n 2>&1 | grep -v amdgpu.ids; done > $O/07_slab_timeline.txt
+NOCF_LIB_PATH=neuraloc_amd/csrc/libnocf_stamps.so timeout 300 python tools/slab_timeline.py mono 2>&1 | grep -v amdgpu.ids > $O/07_mono_timeline.txt
+timeout 300 python tools/time_train.py 2>&1 | grep -v amdgpu.ids > $O/08_train_times.txt
+timeout 300 python tools/time_train.py singlequad 2>&1 | grep -v amdgpu.ids >> $O/08_train_times.txt
+timeout 240 rocprofv3 --kernel-trace --stats -d $O/prof_train -o tr --output-format csv -- python3 tools/time_train.py swarm50 5 > $O/prof_train.log 2>&1
+find $O/prof_train -name "*kernel_stats.csv" -exec cp {} $O/08_train_swarm50_kernel_stats.csv \;
+timeout 600 python tools/f64_time.py 2>&1 | grep -v amdgpu.ids > $O/10_f64_times.txt
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -6 > $O/09_pytest_gpu.log
+rm -rf $O/prof_n1024 $O/prof_n512 $O/prof_sq $O/prof_train $O/pmc_fetch_* $O/pmc_write_*
 ls -la $O
