@@ -2176,8 +2176,11 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         if (e) return (int)e;
         const size_t ldsBytes = (size_t)sp.pp.ldsFloats * 4;
         const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
-        const void* fk = (sp.NT == 2) ? (c2 ? reinterpret_cast<const void*>(rollout_slab_kernel<2, 2>) : reinterpret_cast<const void*>(rollout_slab_kernel<2, 3>))
-                                      : (c2 ? reinterpret_cast<const void*>(rollout_slab_kernel<1, 2>) : reinterpret_cast<const void*>(rollout_slab_kernel<1, 3>));
+        const void* fk = nullptr;
+#define NOCF_SLAB_PICK(NT_, PD_) if (sp.NT == NT_ && (c2 ? 2 : 3) == PD_) fk = s_all ? reinterpret_cast<const void*>(rollout_slab_kernel<NT_, PD_, true>) \
+                                                                                        : reinterpret_cast<const void*>(rollout_slab_kernel<NT_, PD_, false>);
+        NOCF_SLAB_PICK(1, 2) NOCF_SLAB_PICK(1, 3) NOCF_SLAB_PICK(2, 2) NOCF_SLAB_PICK(2, 3)
+#undef NOCF_SLAB_PICK
         e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
         if (env_int("NOCF_DEBUG", 0))
             fprintf(stderr, "[nocf] slab kernel: %d groups x %d members, %d tile(s) of 16 samples, LDS %zu B/workgroup\n", sp.ngroups, SL_G, sp.NT, ldsBytes);
