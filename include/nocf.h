@@ -261,6 +261,11 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob,
                      double* zFull, double* ctrlFull,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Phi.forward (src/Phi.py:91-96) and Phi.getGrad (:99-138) in double: s device [n, d+1] -> value device [n] (nullable),
+ * grad device [n, d+1] (nullable; at least one of the two) */
+int nocf_phi_f64(const NocfPhi64* phi, const double* s, int64_t n, double* value, double* grad,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement hooks (bench.py): between begin and end every nocf_rollout_f32 call records a pair
  * of HIP events on its launch stream immediately around the rollout kernel; end synchronises on
  * them and returns the summed kernel time and the number of launches.  Not thread-safe. */

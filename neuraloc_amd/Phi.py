@@ -136,6 +136,21 @@ class Phi(nn.Module):
             ws = self._ws64 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         return st, keep, ws
 
+    def _phi64(self, x, value):
+        """Phi(s) (n-by-1) or grad Phi (n-by-(d+1)) in double precision (nocf_phi_f64)"""
+        x = _lib.require_device_f64(x, "x")
+        self._guard_no_autograd(x, "Phi.forward" if value else "Phi.getGrad")
+        if x.dim() != 2 or x.shape[1] != self.d + 1:
+            raise ValueError(f"x must be n-by-{self.d + 1}")
+        st, keep, ws = self._c_struct64()
+        n = x.shape[0]
+        out = torch.empty((n, 1) if value else (n, self.d + 1), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().nocf_phi_f64(C.byref(st), _lib.ptr(x), n, _lib.ptr(out) if value else None, None if value else _lib.ptr(out),
+                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+        _lib.check(rc, "nocf_phi_f64")
+        return out
+
     def _guard_no_autograd(self, x, what):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
@@ -144,6 +159,8 @@ class Phi(nn.Module):
 
     def forward(self, x):
         """Phi(s), n-by-1 (src/Phi.py:91-96)."""
+        if isinstance(x, torch.Tensor) and x.dtype == torch.float64:
+            return self._phi64(x, value=True)
         x = _lib.require_device_f32(x, "x")
         self._guard_no_autograd(x, "Phi.forward")
         st, keep, ws = self._c_struct()
@@ -156,6 +173,8 @@ class Phi(nn.Module):
 
     def getGrad(self, x):
         """analytic gradient of Phi wrt (x,t), n-by-(d+1) (src/Phi.py:99-138)."""
+        if isinstance(x, torch.Tensor) and x.dtype == torch.float64:
+            return self._phi64(x, value=False)
         x = _lib.require_device_f32(x, "x")
         self._guard_no_autograd(x, "Phi.getGrad")
         st, keep, ws = self._c_struct()

@@ -2459,4 +2459,32 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob, const double*
     return (int)e;
 }
 
+int nocf_phi_f64(const NocfPhi64* phi, const double* s, int64_t n, double* value, double* grad,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!phi || !s || !workspace || (!value && !grad)) return NOCF_E_NULL;
+    if (!phi->K0 || !phi->b0 || !phi->K || !phi->b || !phi->w || !phi->A || !phi->cw || !phi->cb_dev) return NOCF_E_NULL;
+    if (n < 1 || phi->d < 1 || phi->m < 1 || phi->nTh < 2 || phi->r < 1 || phi->r > 16) return NOCF_E_SHAPE;
+    if (workspace_bytes < nocf_workspace_bytes_f64(phi->d, phi->m, phi->nTh)) return NOCF_E_WORKSPACE;
+    F64Plan pl;
+    int T = 0;
+    const int pref[3] = {n >= 1024 ? 4 : (n >= 512 ? 2 : 1), 2, 1};
+    for (int q = 0; q < 3 && !T; ++q) if ((q == 0 || pref[q] < pref[0]) && make_f64_plan(phi->d, phi->m, phi->nTh, phi->r, 1, pref[q], &pl) == 0) T = pref[q];
+    if (!T) return NOCF_E_LDS;
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+    F64Phi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev, phi->d, phi->m, phi->nTh, phi->r};
+    hipLaunchKernelGGL(f64_pack_kernel, dim3(512), dim3(256), 0, st, pl, P, ws);
+    const size_t ldsBytes = (size_t)pl.ldsDoubles * 8;
+    const void* fk = T == 4 ? reinterpret_cast<const void*>(phi_f64_kernel<4>)
+                   : T == 2 ? reinterpret_cast<const void*>(phi_f64_kernel<2>) : reinterpret_cast<const void*>(phi_f64_kernel<1>);
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e) return (int)e;
+    const double* wsc = ws;
+    long nn = (long)n;
+    void* args[] = {(void*)&pl, (void*)&P, (void*)&wsc, (void*)&s, (void*)&nn, (void*)&value, (void*)&grad};
+    e = hipLaunchKernel(fk, dim3((unsigned)((n + T - 1) / T)), dim3(256), args, ldsBytes, st);
+    if (e) return (int)e;
+    return (int)hipGetLastError();
+}
+
 }  // extern "C"

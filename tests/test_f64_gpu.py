@@ -121,3 +121,22 @@ def test_f64_refuses_mixed_precision_and_training():
     net64 = make_net(g, DEV).to(F64).train()
     with pytest.raises(NotImplementedError, match="evaluation only"):
         na.OCflow(x64, net64, prob, [0.0, 1.0], 4, "rk4", g.meta["alph"])            # autograd in double
+
+
+@pytest.mark.parametrize("nTh,m,n", [(2, 24, 1), (3, 40, 7), (4, 64, 33), (2, 512, 1030)])
+def test_f64_phi_value_and_gradient_against_the_oracle_in_double(nTh, m, n):
+    """Phi.forward / Phi.getGrad in double (src/Phi.py:91-138) on random points s = [x, t]"""
+    d = 8
+    sd = _synth_state_dict64(nTh, m, d, seed=nTh + m)
+    net = na.Phi(nTh=nTh, m=m, d=d, alph=ALPH).to(F64)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    P = orc.PhiParams.from_state_dict(sd, dtype=F64)
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(n, d + 1, generator=g, dtype=F64)
+    with torch.no_grad():
+        val, grad = net(s.to(DEV)), net.getGrad(s.to(DEV))
+        wv, wg = orc.phi_value(P, s), orc.phi_grad(P, s)
+    assert val.shape == (n, 1) and grad.shape == (n, d + 1) and val.dtype == F64
+    assert float((val.cpu() - wv).abs().max()) <= 1e-11 * max(1.0, float(wv.abs().max()))
+    assert float((grad.cpu() - wg).abs().max()) <= 1e-11 * max(1.0, float(wg.abs().max()))
