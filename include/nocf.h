@@ -266,6 +266,10 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob,
 int nocf_phi_f64(const NocfPhi64* phi, const double* s, int64_t n, double* value, double* grad,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* calcLHQW / calcGradpH / calcCtrls in double: the arguments of nocf_prob_eval_f32 with double buffers */
+int nocf_prob_eval_f64(const NocfProb64* prob, int32_t d, const double* x, const double* p, int64_t n,
+                       double* lhqw, double* gradpH, double* ctrls, void* stream);
+
 /* Measurement hooks (bench.py): between begin and end every nocf_rollout_f32 call records a pair
  * of HIP events on its launch stream immediately around the rollout kernel; end synchronises on
  * them and returns the summed kernel time and the number of launches.  Not thread-safe. */

@@ -2487,4 +2487,29 @@ int nocf_phi_f64(const NocfPhi64* phi, const double* s, int64_t n, double* value
     return (int)hipGetLastError();
 }
 
+int nocf_prob_eval_f64(const NocfProb64* prob, int32_t d, const double* x, const double* p, int64_t n,
+                       double* lhqw, double* gradpH, double* ctrls, void* stream) {
+    if (!prob || !x || !p || !prob->xtarget || (!lhqw && !gradpH && !ctrls)) return NOCF_E_NULL;
+    if (n < 1 || d < 1) return NOCF_E_SHAPE;
+    NocfProb p32;
+    p32.kind = prob->kind; p32.obstacle = prob->obstacle; p32.n_agents = prob->n_agents; p32.training = prob->training;
+    p32.r = prob->r; p32.alph_Q = prob->alph_Q; p32.alph_W = prob->alph_W; p32.mass = prob->mass; p32.grav = prob->grav; p32.xtarget = nullptr;
+    DevProb pb32;
+    int rc = fill_prob(&p32, d, &pb32);
+    if (rc) return rc;
+    F64Prob pb{pb32.kind, pb32.obstacle, pb32.nAgents, pb32.training, pb32.agentDim, prob->r, prob->alph_Q, prob->alph_W, prob->mass, prob->grav, prob->xtarget};
+    F64Plan pl;
+    if (make_f64_plan(d, 1, 2, 1, pb.nAgents, 4, &pl) != 0) return NOCF_E_LDS;
+    const size_t ldsBytes = (size_t)pl.ldsDoubles * 8;
+    const void* fk = reinterpret_cast<const void*>(prob_f64_kernel<4>);
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e) return (int)e;
+    long nn = (long)n;
+    int cdim = nocf_ctrl_dim(&p32, d);
+    void* args[] = {(void*)&pl, (void*)&pb, (void*)&x, (void*)&p, (void*)&nn, (void*)&lhqw, (void*)&gradpH, (void*)&ctrls, (void*)&cdim};
+    e = hipLaunchKernel(fk, dim3((unsigned)((n + 3) / 4)), dim3(256), args, ldsBytes, (hipStream_t)stream);
+    if (e) return (int)e;
+    return (int)hipGetLastError();
+}
+
 }  // extern "C"

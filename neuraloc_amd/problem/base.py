@@ -54,7 +54,27 @@ class _ProblemBase:
         st.xtarget = xt.data_ptr()
         return st, [xt]
 
+    def _eval64(self, x, p, want):
+        """the same calls in double precision (nocf_prob_eval_f64)"""
+        x = _lib.require_device_f64(x, "x")
+        p = _lib.require_device_f64(p, "p")
+        n = x.shape[0]
+        st, keep = self._c_struct64(x.device)
+        st32, _k = self._c_struct(x.device)
+        cdim = _lib.lib().nocf_ctrl_dim(C.byref(st32), self.d)
+        kw = dict(device=x.device, dtype=torch.float64)
+        lhqw = torch.empty(n, 4, **kw) if "lhqw" in want else None
+        gp = torch.empty(n, self.d, **kw) if "gradpH" in want else None
+        ct = torch.empty(n, cdim, **kw) if "ctrls" in want else None
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().nocf_prob_eval_f64(C.byref(st), self.d, _lib.ptr(x), _lib.ptr(p), n,
+                                               _lib.ptr(lhqw), _lib.ptr(gp), _lib.ptr(ct), _lib.stream_ptr(x.device))
+        _lib.check(rc, "nocf_prob_eval_f64")
+        return lhqw, gp, ct
+
     def _eval(self, x, p, want):
+        if isinstance(x, torch.Tensor) and x.dtype == torch.float64:
+            return self._eval64(x, p, want)
         x = _lib.require_device_f32(x, "x")
         p = _lib.require_device_f32(p, "p")
         n = x.shape[0]

@@ -140,3 +140,25 @@ def test_f64_phi_value_and_gradient_against_the_oracle_in_double(nTh, m, n):
     assert val.shape == (n, 1) and grad.shape == (n, d + 1) and val.dtype == F64
     assert float((val.cpu() - wv).abs().max()) <= 1e-11 * max(1.0, float(wv.abs().max()))
     assert float((grad.cpu() - wg).abs().max()) <= 1e-11 * max(1.0, float(wg.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["softcorridor", "hardcorridor", "swarm", "midcross4", "singlequad"])
+@pytest.mark.parametrize("training", [False, True])
+def test_f64_problem_calls_against_the_oracle_in_double(name, training):
+    """prob.calcLHQW / calcGradpH / calcCtrls on float64 tensors (the reference's problem objects after --prec double)"""
+    if name not in na.initProb.__globals__["PROBLEM_NAMES"]:
+        pytest.skip("not an initProb problem")
+    torch.manual_seed(2)
+    prob, x0, _, _ = na.initProb(name, 19, 4, 0.5, ALPH, lambda t: t.to(F64).to(DEV))
+    prob.train() if training else prob.eval()
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu().to(F64)
+    g = torch.Generator().manual_seed(9)
+    p = 0.7 * torch.randn(x0.shape, generator=g, dtype=F64)
+    L, H, Q, W = prob.calcLHQW(x0, p.to(DEV))
+    gp, ct = prob.calcGradpH(x0, p.to(DEV)), prob.calcCtrls(x0, p.to(DEV))
+    wL, wH, wQ, wW = orc.prob_LHQW(S, x0.cpu(), p)
+    for got, want in ((L, wL), (H, wH), (Q, wQ), (W, wW), (gp, orc.prob_gradpH(S, x0.cpu(), p)), (ct, orc.prob_ctrls(S, x0.cpu(), p))):
+        want = torch.as_tensor(want, dtype=F64).reshape(got.shape)
+        assert got.dtype == F64
+        assert float((got.cpu() - want).abs().max()) <= 1e-11 * max(1.0, float(want.abs().max()))
