@@ -134,3 +134,29 @@ def test_slab_full_size_against_reference(monkeypatch):
     for j in range(7):
         want = float(g["full/cs"][j])
         assert abs(float(cs[j]) - want) <= 1e-4 * abs(want) + 1e-6
+
+
+@pytest.mark.parametrize("name,training", [("swap12", False), ("swap12", True), ("midcross20", False), ("swarm", True), ("hardcorridor", False)])
+def test_slab_two_tiles_on_other_problems_against_the_tile_kernel(name, training, monkeypatch):
+    """two sample tiles per group (n > 512) on Cross2D / SwarmTraj problems of other sizes: there the x-only cost pass runs on
+    waves 2 and 3 with a different item split (agents x parts) than swarm50's"""
+    if name not in na.initProb.__globals__["PROBLEM_NAMES"]:
+        pytest.skip("not an initProb problem")
+    torch.manual_seed(13)
+    n = 777
+    prob, x0, _, _ = na.initProb(name, n, 8, 0.5, ALPH, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    d = x0.shape[1]
+    net = na.Phi(nTh=2, m=512, d=d, alph=ALPH)
+    net.load_state_dict(_synth_state_dict(2, 512, d, seed=d % 5))
+    net = net.to(DEV).eval()
+    monkeypatch.setenv("NOCF_SLAB", "2")
+    slab = _table(x0, net, prob, [0.0, 1.0], 5, "rk4", ALPH)
+    assert torch.equal(slab, _table(x0, net, prob, [0.0, 1.0], 5, "rk4", ALPH)), "not run-to-run deterministic"
+    monkeypatch.setenv("NOCF_SLAB", "0")
+    tile = _table(x0, net, prob, [0.0, 1.0], 5, "rk4", ALPH)
+    assert _flips(slab, tile) <= max(2, n // 128), f"{name}: {_flips(slab, tile)} samples differ"
+    keep = ~((slab.double() - tile.double()).abs() > 1e-3 + 1e-3 * tile.double().abs()).any(dim=1)
+    for j in range(7):
+        a, b = slab[keep, j].double().mean().item(), tile[keep, j].double().mean().item()
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, f"{name} column {j}: mean {a} vs {b}"
