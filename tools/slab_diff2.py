@@ -28,7 +28,6 @@ rows = off.any(1).nonzero().flatten().tolist()
 print(f"{name} d={d} n={n} nt={nt} {stepper}: rows off {len(rows)}: {rows[:24]}; per column {off.sum(0).tolist()}")
 for r in rows[:3]:
     print("   slab", a[r].tolist(), "\n   tile", b[r].tolist())
-for r in []:
     dist = ((b - a[r]).abs() / (b.abs() + 1e-3)).max(1).values
     j = int(dist.argmin())
-    print("  slab row", r, "is closest to tile row", j, "max rel", float(dist[j]))
+    print("   (closest tile row:", j, "max rel", float(dist[j]), ")")
