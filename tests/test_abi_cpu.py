@@ -48,6 +48,22 @@ def test_argument_errors_are_codes(L):
     assert L.nocf_ctrl_dim(C.byref(pb), 36) == 36
 
 
+def test_double_precision_and_column_sum_entries_check_their_arguments(L):
+    """nocf_rollout_f64 / nocf_phi_f64 / nocf_prob_eval_f64 / nocf_colsum_f32 return codes for bad arguments (nothing is launched)"""
+    for n in ("nocf_rollout_f64", "nocf_phi_f64", "nocf_prob_eval_f64", "nocf_workspace_bytes_f64", "nocf_colsum_f32"):
+        assert hasattr(L, n), n
+    # workspace: K0^T image + (nTh-1) transposed layers, doubles
+    assert L.nocf_workspace_bytes_f64(150, 512, 2) == ((150 + 1) * 512 + 512 * 512) * 8
+    assert L.nocf_workspace_bytes_f64(4, 32, 1) == 0
+    phi, prob = _lib.NocfPhi64(), _lib.NocfProb64()
+    alph = (C.c_double * 6)(*[1.0] * 6)
+    rc = L.nocf_rollout_f64(C.byref(phi), C.byref(prob), None, 4, 0.0, 1.0, 2, _lib.NOCF_RK4, alph, None, None, None, None, None, None, 0, None)
+    assert rc == -1                                          # NOCF_E_NULL: no tensors in the structs
+    assert L.nocf_phi_f64(C.byref(phi), None, 4, None, None, None, 0, None) == -1
+    assert L.nocf_prob_eval_f64(C.byref(prob), 4, None, None, 4, None, None, None, None) == -1
+    assert L.nocf_colsum_f32(None, 10, 4, None, 0, None, 0, None) == -1
+
+
 def test_product_path_refuses_cpu_tensors():
     import neuraloc_amd as na
     net = na.Phi(2, 8, 4)
