@@ -1,0 +1,20 @@
+// nocf_duo.h -- host interface between nocf_kernels.hip (C ABI, dispatch) and nocf_duo.hip (the split-role
+// weight-stationary rollout kernel).  Internal to libnocf.so; nothing here is exported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "nocf.h"
+#include "nocf_dev.h"
+
+// 0 when a network of this shape on a point-agent problem can take the duo kernel (then *bytes = workspace it needs for a
+// rollout of n rows), else an NOCF_E_* code
+int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size_t* bytes);
+
+// Launches the rollout of ra.n rows (in chunks of at most duo_rows_per_launch() rows) on `st`.  Returns 0 and sets
+// *errp (device address of the launch's error word: non-zero after a timed-out exchange) when the kernel was launched,
+// 1 when the shape / problem / workspace / residency does not qualify (nothing was launched: the caller takes another
+// kernel), or a HIP / NOCF_E_* error code.  ev0 / ev1 (optional) are recorded on the stream right around the rollout kernel.
+int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra, float* ws, size_t ws_bytes, hipStream_t st,
+               const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1);
+
+long duo_rows_per_launch(void);

@@ -1,0 +1,964 @@
+// nocf_duo.hip -- weight-STATIONARY rollout for wide networks (m = 512, nTh = 2, point-agent problems), round 3:
+// two ROLE workgroups per CU, two instruction streams per SIMD.
+//
+// Why.  Round 2's slab kernel kept a member's slice of K1 in registers in BOTH orientations (2 x 128 per lane), which
+// forces one wave per SIMD: a single instruction stream that has to do the gathers, the epilogues and the owners' work
+// serially around its MFMAs (0.43 of the fp32 matrix peak; the eight L2 gathers of an evaluation alone were 30 % of it).
+// Here every (group, member) is TWO workgroups of 4 waves, 256 registers per wave, two workgroups per CU:
+//     role A (member c):  W2 = K1[H_c,:] resident (128 AccVGPRs)      role B (member c):  W3 = K1[:,H_c]^T resident
+//       own  sum the 8 partial gradients of the own samples, RK update,    xq  obstacle + pair sums of the own samples (x only)
+//            publish the next stage state S                             P3  a[H_c] = w + hN W3 v        (B = V fragments)
+//       P1   o[H_c] = K0[H_c,:] s + b0   (A = LDS image, B = S fragments)    y = tanh(o) . a   (tanh(o) arrives as TH)
+//            publish u0 = sigma(o) as U, tanh(o) as TH                  P4  partial g = K0[H_c,:]^T y   (A = LDS image)
+//       P2   q[H_c] = W2 u0 + b1         (B = U fragments)                   publish the partial as G
+//            publish v = tanh(q) . w as V
+// so that on every SIMD one wave's L2 waits, epilogues and owner work run under the other wave's MFMAs (the matrix pipe
+// is per SIMD and shared by its two waves).  A group = 8 members x 2 roles = 16 workgroups works on NT tiles of 16
+// samples; hidden units H_c = [64c, 64c+64); wave w of a workgroup owns the 16 features 64c + 16w ...
+//
+// Matrix work: v_mfma_f32_16x16x4_f32, weights as the A operand (M = 16 features), samples as N = 16; a lane's 4 result
+// registers are 4 consecutive features of one sample = the B fragment of the next GEMM.  Every exchange buffer is a
+// list of 1 KiB fragments [64 lanes][4 floats].
+//
+// B operands are STREAMED FROM L2 INTO REGISTERS by every wave for itself (a ring of DU_R fragments in flight, sc1 loads:
+// never through the CU's L1): no LDS staging, no workgroup barrier on the exchange path, and a wave starts multiplying as
+// soon as the first fragments have arrived.  Role A executes no s_barrier after its prologue; role B one per tile (the y
+// fragments of its four waves meet in LDS) and two for the cost pass.
+//
+// Exchange protocol: DATA-TAGGED, no flags.  Every buffer exists twice (parity of the evaluation counter e) and starts as
+// all-ones words (0xFFFFFFFF: a NaN pattern no result has).  A producer stores a fragment into the parity-e buffer; a
+// consumer loads it and re-loads while any word of its 16 bytes is still the sentinel (bounded: on a timeout an error word
+// is set, every wave stops waiting, the host raises).  Slots are RESET (sentinel stores into the other parity) by their
+// producer at a point chosen so that
+//   (H2) every reader of the old contents has finished: the reset of X(e-1) is issued only after the producer has SEEN a
+//        fragment of evaluation e whose existence implies it (the evaluation is an all-to-all dependency cycle
+//        S -> U -> V -> G -> S), and
+//   (H1) no reader can see the old contents again: between the reset and the reader's first poll of that slot (one
+//        evaluation later) the reader has consumed a payload that the same producer wave stored AFTER the reset and after
+//        an intervening `s_waitcnt vmcnt(0)` (vmcnt retires loads and stores in issue order; every streamed GEMM ends in
+//        vmcnt(0)).  Placement: U, TH and V are reset in the P1 epilogue (V one phase early on purpose: its readers, the
+//        role-B waves, consume nothing else from role A before they poll V again); G is reset inside P3 right after its
+//        first V fragment has been validated (so P3's closing vmcnt(0) lies between the reset and the G payload); S and
+//        the cost scalars QW are reset with the next payload (their readers consume U / V / G of the same wave first).
+// A group whose 16 workgroups report the same XCC id keeps payloads in that XCD's L2 (plain stores); any other group
+// writes through (sc1).  Placement-independent; workgroups of a group share blockIdx % 8 (speed only).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include "nocf_duo.h"
+
+#define DU_G 8
+#define DU_KBM 32                  // 16-wide k-blocks of the hidden width (m = 512)
+#define DU_KBD 10                  // 16-wide k-blocks of d+1 (<= 160)
+#define DU_DP 160                  // padded d+1
+#define DU_R 8                     // B fragments in flight per wave (1 KiB each)
+#define DU_NTMAX 4                 // tiles of 16 samples per group (LDS carve of role A)
+#define DU_SENT 0xFFFFFFFFu
+enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P = 7, DUK_XCC = 8 };
+
+// LDS carve (float offsets).  Role A: P1's A-operand image, A, c, the member's slices of b0 / b1 / w, per-tile owner state.
+#define DA_K1 0                                    // [4 waves][10 kb][64 lanes][4]
+#define DA_A (DA_K1 + 4 * DU_KBD * 256)            // [16][160], rows >= r and columns >= d+1 are 0
+#define DA_CW (DA_A + 16 * DU_DP)                  // [160]
+#define DA_VEC (DA_CW + DU_DP)                     // b0 | b1 | w, 64 each
+#define DA_T (DA_VEC + 192)                        // per own sample (2 per tile): the block below
+#define DS_XS 0                                    // [160] stage state (entry d = time)
+#define DS_Z0 160                                  // [160] state at the start of the step
+#define DS_ZA 320                                  // [160] RK accumulator
+#define DS_AZC 480                                 // [160] A^T (A s) + c of the current stage state
+#define DS_ZQ 640                                  // [16]  z = A s
+#define DS_CZ 656                                  // [8]   cost integrals L, HJt, Q, W: value, RK accumulator
+#define DS_PHX 664                                 // [2]   c.s and 1/2 |A s|^2 (final time)
+#define DS_STRIDE 672
+// Role B: P4's A-operand image, w slice, the y fragments, own states, cost-pass partials
+#define DB_K4 0                                    // [10 mt][4 kb][64][4]
+#define DB_VEC (DB_K4 + DU_KBD * 4 * 256)          // w, 64
+#define DB_YF (DB_VEC + 64)                        // [NT][4 waves][64][4]
+#define DB_XB(NT) (DB_YF + (NT) * 1024)            // [NT][2][160]
+#define DB_XP(NT) (DB_XB(NT) + (NT) * 320)         // [NT][<=256 items][2]
+
+struct DuoPlan {
+    int d, D1, r, nAg, NT, ngroups, spin_max, fast;
+    float hN, cb;
+    int mapmode, ldsFloats;
+    long oW2, oW3, oK1, oK4;        // float4 offsets of the images in the workspace
+    long oA, oVec, oCW;             // float offsets: A [16][160], b0 | b1 | w [3][512], c.weight [160]
+    long oPlan, oErr, oXcc, oX, xStride;
+};
+static_assert(sizeof(DuoPlan) % 4 == 0 && sizeof(DuoPlan) / 4 <= 256, "plan copy is done by one 256-thread block");
+
+// images (as in round 2's slab kernel):
+//   W2[c][w][kb][lane] = K1[64c+16w + lane%16][16kb + 4(lane/16) + q]          (P2: out i, contraction j)
+//   W3[c][w][kb][lane] = K1[16kb + 4(lane/16) + q][64c+16w + lane%16]          (P3: out j, contraction i)
+//   K1[c][w][kb][lane] = K0[64c+16w + lane%16][16kb + 4(lane/16) + q]          (P1: out i, contraction dim)
+//   K4[c][mt][kb][lane] = K0[64c + 16kb + 4(lane/16) + q][16mt + lane%16]      (P4: out dim, contraction i in H_c)
+__global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws) {
+    float4* ws4 = reinterpret_cast<float4*>(ws);
+    const int m = 64 * DU_G, D1 = dp.D1;
+    const long nW = (long)DU_G * 4 * DU_KBM * 64, nK1 = (long)DU_G * 4 * DU_KBD * 64, nK4 = (long)DU_G * DU_KBD * 4 * 64;
+    const long total = 2 * nW + nK1 + nK4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long idx = gid; idx < total; idx += stride) {
+        float v[4];
+        long dst;
+        if (idx < 2 * nW) {
+            const bool third = idx >= nW;
+            long q = third ? idx - nW : idx;
+            const int lane = q & 63; q >>= 6;
+            const int kb = q % DU_KBM; q /= DU_KBM;          // q = c*4 + w
+            const int o = (int)q * 16 + (lane & 15);
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * kb + 4 * (lane >> 4) + e;
+                v[e] = third ? P.K[(long)k * m + o] : P.K[(long)o * m + k];
+            }
+            dst = (third ? dp.oW3 : dp.oW2) + (third ? idx - nW : idx);
+        } else if (idx < 2 * nW + nK1) {
+            long q = idx - 2 * nW;
+            const int lane = q & 63; q >>= 6;
+            const int kb = q % DU_KBD; q /= DU_KBD;
+            const int o = (int)q * 16 + (lane & 15);
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * kb + 4 * (lane >> 4) + e;
+                v[e] = (k < D1) ? P.K0[(long)o * D1 + k] : 0.f;
+            }
+            dst = dp.oK1 + (idx - 2 * nW);
+        } else {
+            long q = idx - 2 * nW - nK1;
+            const int lane = q & 63; q >>= 6;
+            const int kb = q & 3; q >>= 2;
+            const int mt = q % DU_KBD; const int cmem = q / DU_KBD;
+            const int dim = 16 * mt + (lane & 15);
+            for (int e = 0; e < 4; ++e) {
+                const int i = 64 * cmem + 16 * kb + 4 * (lane >> 4) + e;
+                v[e] = (dim < D1) ? P.K0[(long)i * D1 + dim] : 0.f;
+            }
+            dst = dp.oK4 + (idx - 2 * nW - nK1);
+        }
+        ws4[dst] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    for (long i = gid; i < 16 * DU_DP; i += stride) {
+        const int row = (int)(i / DU_DP), col = (int)(i % DU_DP);
+        ws[dp.oA + i] = (row < dp.r && col < D1) ? P.A[(long)row * D1 + col] : 0.f;
+    }
+    for (long i = gid; i < 3 * m; i += stride) {
+        const int which = (int)(i / m), col = (int)(i % m);
+        ws[dp.oVec + i] = which == 0 ? P.b0[col] : (which == 1 ? P.b[col] : P.w[col]);
+    }
+    for (long i = gid; i < DU_DP; i += stride) ws[dp.oCW + i] = (i < D1) ? P.cw[i] : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DuoPlan) / 4) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&dp);
+        unsigned v = src[threadIdx.x];
+        if (P.cbp && threadIdx.x == offsetof(DuoPlan, cb) / 4) v = __float_as_uint(*P.cbp);
+        reinterpret_cast<unsigned*>(ws + dp.oPlan)[threadIdx.x] = v;
+    }
+}
+
+// ---- the written-out MFMAs.  The resident weight slice lives in AccVGPRs and is named as SrcA directly (left to itself
+// the compiler copies each operand down with v_accvgpr_read_b32 first: 46..53 cycles per MFMA instead of 32).  What an asm
+// statement does NOT get from the compiler (cdna_hip_programming.md 5.7): wait states and ordering against register-only
+// instructions.  So every string opens with the 2 states a VGPR operand written by a VALU instruction just before needs
+// (free beside a 32-cycle MFMA), an accumulation chain starts with SrcC = 0 (no zero-initialised registers to race with),
+// and DU_FENCE names the accumulators as "+v" operands: their first VALU reader cannot be scheduled above its wait states.
+// (Round 2's operand-less fence is what made that kernel's results depend on the register allocation: see nocf_slab.inc.)
+// tools/mfma_hazard_check.py checks the shipped ISA for both hazards.
+__device__ __forceinline__ void mfma_a0(f32x4& acc, float w_acc, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc) : "a"(w_acc), "v"(b));
+}
+__device__ __forceinline__ void mfma_a(f32x4& acc, float w_acc, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w_acc), "v"(b));
+}
+__device__ __forceinline__ void mfma_v0(f32x4& acc, float w, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(b));
+}
+__device__ __forceinline__ void mfma_v(f32x4& acc, float w, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+}
+#define DU_FENCE2(a, b) asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b))
+#define DU_PIN(v) asm volatile("" : "+s"(v))
+
+struct DCtx {
+    __amdgpu_buffer_rsrc_t xrs;    // this group's exchange area
+    unsigned* err;
+    int fast, spin_max;
+    bool dead;                     // this wave has seen the error word set (or timed out itself): it no longer waits
+};
+
+__device__ __forceinline__ u32x4 du_ld(const DCtx& g, int vbyte, int sbyte) {
+    return __builtin_amdgcn_raw_buffer_load_b128(g.xrs, vbyte, sbyte, 16 /*sc1: not through the CU's L1*/);
+}
+__device__ __forceinline__ void du_st(const DCtx& g, int vbyte, int sbyte, f32x4 v) {
+    u32x4 u;
+    u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
+    if (g.fast) __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 0 /*stays in the XCD's L2*/);
+    else __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 16 /*sc1: write-through*/);
+}
+__device__ __forceinline__ void du_st_sent(const DCtx& g, int vbyte, int sbyte) {
+    const f32x4 sv = {__uint_as_float(DU_SENT), __uint_as_float(DU_SENT), __uint_as_float(DU_SENT), __uint_as_float(DU_SENT)};
+    du_st(g, vbyte, sbyte, sv);
+}
+__device__ __forceinline__ bool du_bad(const u32x4& v) {
+    const unsigned a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+    return (a > b ? a : b) == DU_SENT;
+}
+__device__ __forceinline__ f32x4 du_f(const u32x4& v) {
+    return (f32x4){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+// one more failed poll: back off; true when the caller should stop waiting (timeout, or somebody else already gave up)
+__device__ __forceinline__ bool du_spin(DCtx& g, int& spins, unsigned what) {
+    if (g.dead) return true;
+    __builtin_amdgcn_s_sleep(2);
+    ++spins;
+    if ((spins & 63) == 0) {
+        const unsigned ev = __builtin_amdgcn_readfirstlane(__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (ev != 0u) { g.dead = true; return true; }
+    }
+    if (spins > g.spin_max) { atomicExch(g.err, 0x3000u + what); g.dead = true; return true; }
+    return false;
+}
+
+// acc = sum over NKB k-blocks of (A fragment) x (B fragment kb of the exchange buffer at byte offset sbyte, streamed from L2).
+// A fragments: AccVGPRs W[kb] (LDSA false) or LDS float4s at index a4 + kb*64 (LDSA true).  Two accumulation chains (a
+// dependent v_mfma_f32_16x16x4_f32 may issue 40 cycles behind its producer; the chains alternate at 32).  A fragment that
+// still shows a sentinel word is polled alone, then the rest of the ring is requested again (the requests behind a stale
+// fragment are most likely stale too).  after_first() runs once the first fragment has been validated.
+template <int NKB, bool LDSA, class F0>
+__device__ __forceinline__ f32x4 du_gemm(DCtx& g, const f32x4 (&W)[DU_KBM], int a4, int vbyte, int sbyte, unsigned what, F0&& after_first) {
+    u32x4 ring[DU_R];
+#pragma unroll
+    for (int i = 0; i < DU_R; ++i) if (i < NKB) ring[i] = du_ld(g, vbyte, sbyte + i * 1024);
+    const float4* L4 = reinterpret_cast<const float4*>(lds);
+    float4 ar[4];
+    if (LDSA) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ar[i] = L4[a4 + (i < NKB ? i : 0) * 64];
+    }
+    f32x4 a0, a1;
+    int spins = 0;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (LDSA && kb + 3 < NKB) ar[(kb + 3) & 3] = L4[a4 + (kb + 3) * 64];
+        if (__builtin_expect(__any(du_bad(ring[kb % DU_R])), 0)) {
+            while (true) {
+                if (du_spin(g, spins, what)) break;
+                ring[kb % DU_R] = du_ld(g, vbyte, sbyte + kb * 1024);
+                if (!__any(du_bad(ring[kb % DU_R]))) break;
+            }
+#pragma unroll
+            for (int i = 1; i < DU_R; ++i) if (kb + i < NKB) ring[(kb + i) % DU_R] = du_ld(g, vbyte, sbyte + (kb + i) * 1024);
+        }
+        const f32x4 b = du_f(ring[kb % DU_R]);
+        if (LDSA) {
+            const float4 w = ar[kb & 3];
+            if (kb == 0) { mfma_v0(a0, w.x, b[0]); mfma_v0(a1, w.y, b[1]); after_first(); }
+            else { mfma_v(a0, w.x, b[0]); mfma_v(a1, w.y, b[1]); }
+            mfma_v(a0, w.z, b[2]); mfma_v(a1, w.w, b[3]);
+        } else {
+            if (kb == 0) { mfma_a0(a0, W[0][0], b[0]); mfma_a0(a1, W[0][1], b[1]); after_first(); }
+            else { mfma_a(a0, W[kb][0], b[0]); mfma_a(a1, W[kb][1], b[1]); }
+            mfma_a(a0, W[kb][2], b[2]); mfma_a(a1, W[kb][3], b[3]);
+        }
+        if (kb + DU_R < NKB) ring[kb % DU_R] = du_ld(g, vbyte, sbyte + (kb + DU_R) * 1024);
+    }
+    DU_FENCE2(a0, a1);
+    return a0 + a1;
+}
+struct DuNop { __device__ __forceinline__ void operator()() const {} };
+
+// Diagnostic build only (-DNOCF_STAMPS): per-wave shader-clock timeline of ONE evaluation of group 0 / member 0 (both roles):
+// tools/duo_timeline.py.  The production library contains no stamp.
+#ifdef NOCF_STAMPS
+#define DTL(id) do { if (tlp && lane == 0) tlp[id] = clock64(); } while (0)
+#else
+#define DTL(id) do { } while (0)
+#endif
+
+// ---- x-only running-cost terms (Cross2D.py:89-160, SwarmTraj.py:89-162): cyclic pairing, agent a meets (a+j) mod N
+__device__ __forceinline__ float du_pair_term(float s2, float thr, float thr2, float nden_l2e) {
+    // branch-free: v_sqrt_f32 / v_exp_f32 (1 ulp each); the mask is the reference's `dist < thr`, entries equal to 1 are dropped
+    const float dist = __builtin_amdgcn_sqrtf(s2);
+    const float e = __builtin_amdgcn_exp2f((dist * dist) * nden_l2e);
+    return (s2 < thr2 && dist < thr && e != 1.f) ? e : 0.f;
+}
+// Thread item (sample, agent a, part): the agent meets the partners (a + j) mod N, j = 1..J = (N-1)/2 (every unordered pair once),
+// for even N also the opposite agent j = N/2 from the lower half; the P parts split that range.  Part 0 adds the agent's obstacle term.
+struct DXPar { float thr, thr2, nden_l2e, den, thr_pair2; int N, J, JJ, P, lgP, Jp; bool obs, wantW; };
+__device__ __forceinline__ DXPar du_x_params(const DevProb& pb, int PD) {
+    DXPar xp;
+    xp.N = pb.nAgents;
+    xp.obs = pb.obstacle != NOCF_OBS_NONE && (PD == 2 || pb.alphQ > 0.0);
+    xp.wantW = want_W(pb) && xp.N >= 2;
+    xp.den = (float)(2.0 * pb.r * pb.r);
+    const double fac = pb.training ? (PD == 3 ? 3.2 : 2.2) : 2.0;
+    xp.thr = (float)(fac * pb.r);
+    xp.thr2 = xp.thr * xp.thr * 1.000002f;
+    xp.nden_l2e = -1.4426950408889634f / xp.den;
+    xp.thr_pair2 = (float)((pb.training ? 2.2 : 2.0) * pb.r);        // the two-agent form of calcW
+    xp.J = (xp.N - 1) >> 1;
+    xp.JJ = (xp.wantW && xp.N > 2) ? xp.J + (((xp.N & 1) == 0) ? 1 : 0) : 0;
+    xp.P = 1; xp.lgP = 0;
+    while (xp.P < 4 && 2 * xp.N * xp.P * 2 <= 256) { xp.P *= 2; ++xp.lgP; }      // items per tile = 2 samples x N x P <= 256
+    xp.Jp = (xp.JJ + xp.P - 1) / xp.P;
+    return xp;
+}
+template <int PD>
+__device__ __forceinline__ void du_x_item(const DevProb& pb, const DXPar& xp, const float* __restrict__ x /* LDS row of the sample */, int a, int part,
+                                          float& qacc, float& wacc) {
+    const int N = xp.N;
+    float xa[PD];
+#pragma unroll
+    for (int k = 0; k < PD; ++k) xa[k] = x[PD * a + k];
+    if (part == 0 && xp.obs) qacc += (PD == 2) ? obstacle_cross2d(pb, xa[0], xa[1]) : obstacle_swarm(pb, xa[0], xa[1], xa[PD - 1]);
+    if (!xp.wantW) return;
+    if (N == 2) {
+        if (a == 0 && part == 0) {
+            float s2 = 0.f;
+            for (int k = 0; k < PD; ++k) { const float e = x[k] - x[PD + k]; s2 += e * e; }
+            const float dist = sqrtf(s2);
+            if (dist < xp.thr_pair2) wacc += expf(-(dist * dist) / xp.den);
+        }
+        return;
+    }
+    const int jlo = 1 + part * xp.Jp;
+    int jhi = jlo + xp.Jp; if (jhi > xp.JJ + 1) jhi = xp.JJ + 1;                   // partners [jlo, jhi)
+    if (jhi == xp.JJ + 1 && xp.JJ > xp.J && a >= (N >> 1)) --jhi;                   // the opposite agent counts from the lower half only
+    int b = a + jlo; while (b >= N) b -= N;
+    const float* xbp = x + PD * b;
+    const float* xend = x + PD * N;
+    constexpr int XW = 5;                                   // partners per round (their LDS reads are in flight together)
+    for (int j = jlo; j < jhi; j += XW) {
+        float xb[XW][PD];
+#pragma unroll
+        for (int u = 0; u < XW; ++u) {
+#pragma unroll
+            for (int k = 0; k < PD; ++k) xb[u][k] = xbp[k];
+            xbp += PD; if (xbp >= xend) xbp -= PD * N;
+        }
+        float s2[XW];
+        bool near = false;
+#pragma unroll
+        for (int u = 0; u < XW; ++u) {
+            float a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < PD; ++k) { const float e = xa[k] - xb[u][k]; a2 += e * e; }
+            s2[u] = (j + u < jhi) ? a2 : 3.0e38f;
+            near |= s2[u] < xp.thr2;
+        }
+        // pairs within the interaction radius are rare: the square roots and exponentials are skipped for the whole wave unless
+        // one of its pairs of this round is near -- every skipped term is exactly 0
+        if (__any(near)) {
+#pragma unroll
+            for (int u = 0; u < XW; ++u) wacc += du_pair_term(s2[u], xp.thr, xp.thr2, xp.nden_l2e);
+        }
+    }
+}
+
+// byte offsets of the exchange kinds inside a group's area (functions of NT), all pinned in scalar registers by the kernel
+struct DXOff { int S, U, T, V, G, Q, P; };
+__host__ __device__ inline long duo_x_layout(int NT, DXOff* o) {
+    long x = 0;
+    auto take = [&](long nfl) { const long at = x; x += (nfl + 63) / 64 * 64; return at; };
+    const long s = take(2L * NT * DU_KBD * 256), u = take(2L * NT * DU_KBM * 256), t = take(2L * NT * DU_KBM * 256), v = take(2L * NT * DU_KBM * 256);
+    const long gg = take(2L * NT * DU_G * DU_KBD * 256), q = take(2L * NT * DU_G * 4), p = take((long)NT * DU_G * 4 * 16);
+    if (o) { o->S = (int)(s * 4); o->U = (int)(u * 4); o->T = (int)(t * 4); o->V = (int)(v * 4); o->G = (int)(gg * 4); o->Q = (int)(q * 4); o->P = (int)(p * 4); }
+    return x;                                      // floats per group
+}
+
+struct DuoRun { long row0, n_total; };             // rows of this launch inside the caller's batch (chunked launches; sAll indexing)
+
+template <int PD, bool REC>
+__global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __restrict__ dpp, DevProb pb, float* ws, RollArgs ra, DuoRun rr) {
+    const DuoPlan& dp = *dpp;
+    const int bid = blockIdx.x;
+    const int jb = bid >> 3;
+    const int group = (bid & 7) + 8 * (jb >> 4);
+    if (group >= dp.ngroups) return;
+    const int within = jb & 15;
+    const int member = dp.mapmode ? (within >> 1) : (within & 7);
+    const int role = dp.mapmode ? (within & 1) : (within >> 3);
+    const int tid = threadIdx.x, lane = tid & 63, slot = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int NT = dp.NT; DU_PIN(NT);
+    const int d = dp.d, D1 = dp.D1;
+    const float hN = dp.hN;
+    DXOff xo;
+    (void)duo_x_layout(NT, &xo);
+    int xS = xo.S, xU = xo.U, xT = xo.T, xV = xo.V, xG = xo.G, xQ = xo.Q, xP = xo.P;
+    DU_PIN(xS); DU_PIN(xU); DU_PIN(xT); DU_PIN(xV); DU_PIN(xG); DU_PIN(xQ); DU_PIN(xP);
+    DCtx g;
+    g.xrs = __builtin_amdgcn_make_buffer_rsrc(ws + dp.oX + (long)group * dp.xStride, 0, (int)(dp.xStride * 4), 0x00020000);
+    g.err = reinterpret_cast<unsigned*>(ws) + dp.oErr;
+    g.fast = 0; g.spin_max = dp.spin_max; g.dead = false;
+    const float4* ws4 = reinterpret_cast<const float4*>(ws);
+    float4* L4 = reinterpret_cast<float4*>(lds);
+    const int vb = lane * 16;                                   // this lane's 16 bytes of a fragment
+#ifdef NOCF_STAMPS
+    unsigned long long* tlp = nullptr;
+    const int e_probe = (ra.nt / 2) * ((ra.stepper == NOCF_RK4) ? 4 : 1) + 2;
+#define DTL_EPOCH(e_) tlp = (ra.stamps && group == 0 && member == 0 && (e_) == e_probe) ? ra.stamps + (role * 4 + wave) * 128 : nullptr
+#else
+#define DTL_EPOCH(e_) do { } while (0)
+#endif
+
+    // ---- the resident weight slice: 128 AccVGPRs per lane, loaded once (role A: K1[H_c,:], role B: K1[:,H_c]^T)
+    f32x4 W[DU_KBM];
+    {
+        const long bw = (role ? dp.oW3 : dp.oW2) + (long)(member * 4 + wave) * DU_KBM * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < DU_KBM; ++kb) { const float4 a = ws4[bw + kb * 64]; W[kb] = (f32x4){a.x, a.y, a.z, a.w}; }
+    }
+    // ---- where do the 16 workgroups of my group run?  (same-XCD groups keep the exchange in that XCD's L2)
+    if (dp.fast && wave == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc = (xcc & 0xfu) + 1u;
+        unsigned* tab = reinterpret_cast<unsigned*>(ws) + dp.oXcc + (long)group * 16;
+        if (lane == 0) __hip_atomic_store(tab + within, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        unsigned v = 0;
+        while (true) {
+            v = __hip_atomic_load(tab + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v != 0u)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > dp.spin_max) { if (lane == 0) atomicExch(g.err, 0x3000u + DUK_XCC); break; }
+        }
+        if (lane == 0) lds[0] = __all(v == xcc) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    g.fast = dp.fast && lds[0] != 0.f;
+    __syncthreads();
+
+    const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
+    const long rowg = (long)group * 16 * NT;                    // first row (of this launch) of the group
+    auto own_row = [&](int t, int j) -> long { return rowg + 16 * t + 2 * member + j; };
+
+    if (role == 0) {
+        // =====================================================================================================
+        // role A
+        // =====================================================================================================
+        for (int i = tid; i < 4 * DU_KBD * 64; i += 256) L4[(DA_K1 >> 2) + i] = ws4[dp.oK1 + (long)member * 4 * DU_KBD * 64 + i];
+        for (int i = tid; i < 16 * DU_DP; i += 256) lds[DA_A + i] = ws[dp.oA + i];
+        if (tid < DU_DP) lds[DA_CW + tid] = ws[dp.oCW + tid];
+        if (tid < 192) lds[DA_VEC + tid] = ws[dp.oVec + (tid >> 6) * 64 * DU_G + member * 64 + (tid & 63)];
+        for (int i = tid; i < 2 * NT * DS_STRIDE; i += 256) lds[DA_T + i] = 0.f;
+        __syncthreads();
+        for (int i = tid; i < 2 * NT * DU_DP; i += 256) {
+            const int s = i / DU_DP, c = i - s * DU_DP;
+            long row = own_row(s >> 1, s & 1); if (row >= ra.n) row = ra.n - 1;
+            const float v = (c < d) ? ra.x[row * d + c] : 0.f;
+            lds[DA_T + s * DS_STRIDE + DS_Z0 + c] = v;
+            lds[DA_T + s * DS_STRIDE + DS_XS + c] = (c == d) ? (float)ra.t0 : v;
+        }
+        __syncthreads();
+        // (no s_barrier below this line in role A: every wave runs on its own)
+        const float cAlphQ = (float)pb.alphQ, cAlphW = (float)pb.alphW;
+        const bool cWantW = want_W(pb);
+        const float c16 = (float)(1.0 / 6.0), c26 = (float)(2.0 / 6.0);
+        // Owner units are SAMPLES: own sample s = 2 t + j (sample 2 member + j of tile t) belongs to wave s & 3; lane l < 40 of that
+        // wave keeps the piece dims 4 l .. 4 l + 3 = (dim tile mt = l / 4, slot sl = l % 4) of the sample.
+        const bool pact = lane < 40;
+        const int pmt = lane >> 2, psl = lane & 3, pi = 4 * lane;
+        const int pd_lane = d >> 2, pd_e = d & 3;                     // where g[d] = dPhi/dt sits
+
+        // g of own sample s at evaluation parity parG: fixed-order sum of the 8 members' partials + A^T (A s) + c
+        auto gather_g = [&](int s, int parG) -> f32x4 {
+            const int t = s >> 1, j = s & 1;
+            const int lp = (psl * 16 + 2 * member + j) * 16;
+            const int sb = xG + ((parG * NT + t) * DU_G * DU_KBD + (pact ? pmt : 0)) * 1024;
+            u32x4 pv[DU_G];
+            int spins = 0;
+            while (true) {
+                bool bad = false;
+#pragma unroll
+                for (int mem = 0; mem < DU_G; ++mem) pv[mem] = du_ld(g, lp, sb + mem * DU_KBD * 1024);
+#pragma unroll
+                for (int mem = 0; mem < DU_G; ++mem) bad |= du_bad(pv[mem]);
+                if (!__any(bad && pact)) break;
+                if (du_spin(g, spins, DUK_G)) break;
+            }
+            f32x4 gs = du_f(pv[0]);
+#pragma unroll
+            for (int mem = 1; mem < DU_G; ++mem) gs += du_f(pv[mem]);
+            const float4 z = L4[(DA_T + s * DS_STRIDE + DS_AZC + (pact ? pi : 0)) >> 2];
+            gs += (f32x4){z.x, z.y, z.z, z.w};
+            return gs;
+        };
+
+        // the owner's step: gradient of evaluation e-1 -> RK update -> stage state of evaluation e published -> costs integrated
+        auto owner_step = [&](int s, int e, float hs, int pst, float t_pub) {
+            const int t = s >> 1, j = s & 1;
+            const int parG = (e - 1) & 1, parS = e & 1;
+            const bool rk_last = (pst == nstage - 1);
+            const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
+            const float rk_wx = (pst < 2) ? 0.5f : 1.f;
+            DTL(40 * t + 0);
+            const f32x4 gs = gather_g(s, parG);
+            DTL(40 * t + 1);
+            const int sbase = DA_T + s * DS_STRIDE;
+            f32x4 xs = {0.f, 0.f, 0.f, 0.f};
+            if (pact) {
+                const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2];
+                const float z0[4] = {z04.x, z04.y, z04.z, z04.w};
+                float zA[4] = {zA4.x, zA4.y, zA4.z, zA4.w}, zn[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int i = pi + e4;
+                    const float K = hs * -gs[e4];                          // dx = -grad_p H = -p (src/OCflow.py:134, :143-184)
+                    float x_;
+                    zn[e4] = z0[e4];
+                    if (rk_last) { x_ = (nstage == 1 ? z0[e4] : zA[e4]) + rk_wa * K; zn[e4] = x_; }
+                    else { zA[e4] = (pst == 0 ? z0[e4] : zA[e4]) + rk_wa * K; x_ = z0[e4] + rk_wx * K; }
+                    xs[e4] = (i < d) ? x_ : (i == d ? t_pub : 0.f);
+                    if (i >= d) { zn[e4] = 0.f; zA[e4] = 0.f; }
+                }
+                const int lp = (psl * 16 + 2 * member + j) * 16;
+                du_st(g, lp, xS + ((parS * NT + t) * DU_KBD + pmt) * 1024, xs);
+                du_st_sent(g, lp, xS + (((parS ^ 1) * NT + t) * DU_KBD + pmt) * 1024);
+                if (rk_last) L4[(sbase + DS_Z0 + pi) >> 2] = make_float4(zn[0], zn[1], zn[2], zn[3]);
+                else L4[(sbase + DS_ZA + pi) >> 2] = make_float4(zA[0], zA[1], zA[2], zA[3]);
+                L4[(sbase + DS_XS + pi) >> 2] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+                // training: the stage input of evaluation e (index e-1); the terminal evaluation is not recorded
+                if (REC && ra.sAll && e <= ra.nt * nstage && own_row(t, j) < ra.n) {
+                    float* dst = ra.sAll + (((long)(e - 1)) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 1);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 <= d) dst[pi + e4] = xs[e4];
+                }
+            }
+            DTL(40 * t + 2);
+            // ---- cost side of evaluation e-1 (after the state has been sent): sum p^2, dPhi/dt, the x-only terms from role B
+            float q0 = 0.f;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) if (pact && pi + e4 < d) q0 += gs[e4] * gs[e4];
+            const float sp2 = sum64(q0);
+            const float gdv = pd_e == 0 ? gs[0] : (pd_e == 1 ? gs[1] : (pd_e == 2 ? gs[2] : gs[3]));
+            const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gdv), pd_lane));
+            // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
+            float q_ = 0.f, w_ = 0.f;
+            {
+                const int ob = xQ + (((parG * NT + t) * DU_G + member) * 4 + 2 * j) * 4;
+                int spins = 0;
+                while (true) {
+                    const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, ob, 16);
+                    q_ = __uint_as_float(v2[0]); w_ = __uint_as_float(v2[1]);
+                    if (!__any(v2[0] == DU_SENT || v2[1] == DU_SENT)) break;
+                    if (du_spin(g, spins, DUK_Q)) break;
+                }
+            }
+            if (lane < 4) {
+                // calcLHQW of the point-agent problems (Cross2D.py:73-87 returns the scaled Q, SwarmTraj.py:71-87 the raw one)
+                const float Qs = cAlphQ * q_;
+                const float Wv = cWantW ? w_ : 0.f;
+                float Lg = 0.5f * sp2 + Qs;
+                if (cWantW) Lg = Lg + cAlphW * Wv;
+                const float H = -Lg + sp2;
+                const float val = (lane == 0) ? Lg : (lane == 1) ? fabsf(gt - H) : (lane == 2) ? (PD == 2 ? Qs : q_) : Wv;
+                const float K = hs * val;
+                float* cz = lds + sbase + DS_CZ + lane;                     // [0..3] value, [4..7] RK accumulator
+                const float cz0 = cz[0], czA = cz[4];
+                if (rk_last) cz[0] = (nstage == 1 ? cz0 : czA) + rk_wa * K;
+                else cz[4] = (pst == 0 ? cz0 : czA) + rk_wa * K;
+            }
+            DTL(40 * t + 3);
+        };
+
+        // z = A s and A^T z + c of own sample s at its CURRENT stage state (needed when the gradient of this evaluation arrives)
+        auto azc_step = [&](int s, bool fin) {
+            const int sbase = DA_T + s * DS_STRIDE;
+            {
+                const int q = lane >> 2, part = lane & 3;            // row of A, quarter of the dims (10 float4 each)
+                float acc = 0.f;
+#pragma unroll 5
+                for (int i4 = 0; i4 < 10; ++i4) {
+                    const float4 a = L4[((DA_A + q * DU_DP) >> 2) + part * 10 + i4], x4 = L4[((sbase + DS_XS) >> 2) + part * 10 + i4];
+                    acc += (a.x * x4.x + a.y * x4.y) + (a.z * x4.z + a.w * x4.w);
+                }
+                acc = sum4(acc);
+                if (part == 0) lds[sbase + DS_ZQ + q] = acc;
+            }
+            float lin = 0.f;
+            if (pact) {
+                const float4 c4 = L4[(DA_CW + pi) >> 2];
+                float o[4] = {c4.x, c4.y, c4.z, c4.w};
+                for (int q = 0; q < dp.r; ++q) {
+                    const float z = lds[sbase + DS_ZQ + q];
+                    const float4 a = L4[(DA_A + q * DU_DP + pi) >> 2];
+                    o[0] += a.x * z; o[1] += a.y * z; o[2] += a.z * z; o[3] += a.w * z;
+                }
+                L4[(sbase + DS_AZC + pi) >> 2] = make_float4(o[0], o[1], o[2], o[3]);
+                if (fin) { const float4 x4 = L4[(sbase + DS_XS + pi) >> 2]; lin = (c4.x * x4.x + c4.y * x4.y) + (c4.z * x4.z + c4.w * x4.w); }
+            }
+            if (fin) {                                            // Phi's linear and quadratic terms at the final time (src/Phi.py:91-96)
+                const float ls = sum64(lin);
+                if (lane == 0) {
+                    float qd = 0.f;
+                    for (int q = 0; q < dp.r; ++q) { const float z = lds[sbase + DS_ZQ + q]; qd += 0.5f * z * z; }
+                    lds[sbase + DS_PHX] = ls;
+                    lds[sbase + DS_PHX + 1] = qd;
+                }
+            }
+        };
+
+        // ---- evaluation 1: the stage states come straight from x
+        for (int s = wave; s < 2 * NT; s += 4) {
+            const int t = s >> 1, j = s & 1, sbase = DA_T + s * DS_STRIDE;
+            if (pact) {
+                const float4 x4 = L4[(sbase + DS_XS + pi) >> 2];
+                du_st(g, (psl * 16 + 2 * member + j) * 16, xS + ((1 * NT + t) * DU_KBD + pmt) * 1024, (f32x4){x4.x, x4.y, x4.z, x4.w});
+            }
+            if (REC && ra.sAll && own_row(t, j) < ra.n)
+                for (int i = lane; i <= d; i += 64) ra.sAll[(rr.row0 + own_row(t, j)) * (d + 1) + i] = lds[sbase + DS_XS + i];
+        }
+
+        double tk = ra.t0;
+        int e = 0;
+        float p_hs = 0.f; int p_st = 0;
+        for (int k = 0; k <= ra.nt; ++k) {
+            const bool fin = (k == ra.nt);
+            const double t1k = tk + ra.h;
+            const double hsd = t1k - tk;                           // stepRK4 re-derives h = t1 - t0 (src/OCflow.py:170)
+            for (int st = 0; st < (fin ? 1 : nstage); ++st) {
+                ++e;
+                const int par = e & 1;
+                DTL_EPOCH(e);
+                // time of this evaluation: stepRK4's t0, t0 + h/2, t0 + h/2, t0 + h in double (src/OCflow.py:157-184); the terminal
+                // evaluation runs at tspan[1] (src/OCflow.py:62)
+                const double te = fin ? ra.t1 : ((nstage == 1 || st == 0) ? tk : (st == 3 ? tk + hsd : tk + hsd / 2));
+                for (int t = 0; t < NT; ++t) {
+                    if (e > 1) {
+                        if (((2 * t) & 3) == wave) owner_step(2 * t, e, p_hs, p_st, (float)te);
+                        if (((2 * t + 1) & 3) == wave) owner_step(2 * t + 1, e, p_hs, p_st, (float)te);
+                    }
+                    // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
+                    DTL(40 * t + 4);
+                    const f32x4 acc = du_gemm<DU_KBD, true>(g, W, (DA_K1 >> 2) + wave * DU_KBD * 64 + lane, vb, xS + ((par * NT + t) * DU_KBD) * 1024, DUK_S, [&]() { DTL(40 * t + 5); });
+                    DTL(40 * t + 6);
+                    const float4 b0s = L4[(DA_VEC >> 2) + 4 * wave + slot];    // bias of this lane's 4 features 16 wave + 4 slot + e
+                    const float b0v[4] = {b0s.x, b0s.y, b0s.z, b0s.w};
+                    f32x4 sg, th;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) { float s_, t_; act_pair(acc[e4] + b0v[e4], s_, t_); sg[e4] = s_; th[e4] = t_; }
+                    const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, fr = (((par ^ 1) * NT + t) * DU_KBM + 4 * member + wave) * 1024;
+                    du_st(g, vb, xU + fo, sg);
+                    du_st(g, vb, xT + fo, th);
+                    du_st_sent(g, vb, xU + fr);
+                    du_st_sent(g, vb, xT + fr);
+                    du_st_sent(g, vb, xV + fr);                     // (V one phase early: header, H1)
+                    DTL(40 * t + 7);
+                }
+                DTL(8);
+                for (int s = wave; s < 2 * NT; s += 4) azc_step(s, fin);
+                DTL(9);
+                for (int t = 0; t < NT; ++t) {
+                    // ================= P2: q = K1[H_c,:] u0 + b1 ; v = tanh(q) . w =================
+                    DTL(40 * t + 10);
+                    const f32x4 acc = du_gemm<DU_KBM, false>(g, W, 0, vb, xU + ((par * NT + t) * DU_KBM) * 1024, DUK_U, [&]() { DTL(40 * t + 11); });
+                    DTL(40 * t + 12);
+                    const float4 b1s = L4[((DA_VEC + 64) >> 2) + 4 * wave + slot], wvs = L4[((DA_VEC + 128) >> 2) + 4 * wave + slot];
+                    const float b1v[4] = {b1s.x, b1s.y, b1s.z, b1s.w}, wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
+                    f32x4 v;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) v[e4] = tanh_fast(acc[e4] + b1v[e4]) * wv[e4];
+                    du_st(g, vb, xV + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, v);
+                    DTL(40 * t + 13);
+                    if (fin) {
+                        // w . u_1 = w . (u_0 + hN sigma(q)) over this wave's 16 features (src/Phi.py:91-96): own u_0 fragment back from the exchange
+                        const f32x4 u0 = du_f(du_ld(g, vb, xU + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024));
+                        float pr = 0.f;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) pr += wv[e4] * (u0[e4] + hN * sigma_act(acc[e4] + b1v[e4]));
+                        pr += __shfl_xor(pr, 16); pr += __shfl_xor(pr, 32);
+                        if (lane < 16) {
+                            const unsigned pu = __float_as_uint(pr);
+                            const int off = xP + (((t * DU_G + member) * 4 + wave) * 16 + lane) * 4;
+                            if (g.fast) __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 16);
+                        }
+                    }
+                }
+                p_hs = (float)hsd; p_st = st;
+                if (fin) break;
+            }
+            tk += ra.h;
+        }
+        // ---- terminal costs of the own samples (src/OCflow.py:58-76): gradient and Phi of the terminal evaluation
+        for (int s = wave; s < 2 * NT; s += 4) {
+            const int t = s >> 1, j = s & 1, sbase = DA_T + s * DS_STRIDE;
+            const f32x4 gs = gather_g(s, e & 1);
+            float r2 = 0.f, hg = 0.f;
+            if (pact) {
+                const float4 z = L4[(sbase + DS_Z0 + pi) >> 2];
+                const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 < d) { const float res = zz[e4] - pb.xtarget[pi + e4]; r2 += res * res; hg += fabsf(gs[e4] - ra.a0 * res); }
+            }
+            const float cG = 0.5f * sum64(r2), hj = sum64(hg);
+            // w . u_1: the 8 members x 4 waves partials of this sample (lanes 0..31: member lane / 4, wave lane % 4)
+            float ph;
+            {
+                unsigned u = 0;
+                int spins = 0;
+                const int off = xP + ((t * DU_G * 4 + (lane & 31)) * 16 + 2 * member + j) * 4;
+                while (true) {
+                    u = __builtin_amdgcn_raw_buffer_load_b32(g.xrs, off, 0, 16);
+                    if (!__any(u == DU_SENT)) break;
+                    if (du_spin(g, spins, DUK_P)) break;
+                }
+                ph = sum64(lane < 32 ? __uint_as_float(u) : 0.f);
+            }
+            const long row = own_row(t, j);
+            if (row < ra.n) {
+                if (lane == 0 && ra.persample) {
+                    const float phi = ph + lds[sbase + DS_PHX + 1] + lds[sbase + DS_PHX] + dp.cb;
+                    const float* cz = lds + sbase + DS_CZ;
+                    float* op = ra.persample + row * 7;
+                    op[0] = cz[0]; op[1] = cG; op[2] = cz[1];
+                    op[3] = fabsf(phi - ra.a0 * cG);
+                    op[4] = hj;
+                    op[5] = cz[2]; op[6] = cz[3];
+                }
+                if (ra.z_out)
+                    for (int i = lane; i < d + 4; i += 64)
+                        ra.z_out[row * (d + 4) + i] = (i < d) ? lds[sbase + DS_Z0 + i] : lds[sbase + DS_CZ + (i - d)];
+            }
+        }
+    } else {
+        // =====================================================================================================
+        // role B
+        // =====================================================================================================
+        for (int i = tid; i < DU_KBD * 4 * 64; i += 256) L4[(DB_K4 >> 2) + i] = ws4[dp.oK4 + (long)member * DU_KBD * 4 * 64 + i];
+        if (tid < 64) lds[DB_VEC + tid] = ws[dp.oVec + 2 * 64 * DU_G + member * 64 + tid];
+        __syncthreads();
+        const float4 wvs = L4[(DB_VEC >> 2) + 4 * wave + slot];
+        const float wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
+        const DXPar xp = du_x_params(pb, PD);
+        const int NP = xp.N * xp.P, IT = 2 * NP;                 // cost-pass items per sample / per tile
+        const int lXB = DB_XB(NT), lXP = DB_XP(NT);
+        const int E = ra.nt * nstage + 1;
+        for (int e = 1; e <= E; ++e) {
+            const bool fin = (e == E);
+            const int par = e & 1;
+            DTL_EPOCH(e);
+            DTL(20);
+            if (!fin) {
+                // ================= x-only cost terms of the own samples at the state of evaluation e =================
+                for (int pb0 = 0; pb0 < NT * 80; pb0 += 256) {      // (uniform trip count: the polls inside stay wave-uniform)
+                    const int p = pb0 + tid;
+                    const bool valid = p < NT * 80;
+                    const int pc = valid ? p : 0;
+                    const int t = pc / 80, q = pc - t * 80, j = q >= 40 ? 1 : 0, r_ = q - 40 * j, mt = r_ >> 2, sl = r_ & 3;
+                    const int off = xS + ((par * NT + t) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16;
+                    u32x4 v;
+                    int spins = 0;
+                    while (true) {
+                        v = du_ld(g, off, 0);
+                        if (!__any(du_bad(v))) break;
+                        if (du_spin(g, spins, DUK_S)) break;
+                    }
+                    const f32x4 f = du_f(v);
+                    if (valid) L4[(lXB + (t * 2 + j) * DU_DP + 16 * mt + 4 * sl) >> 2] = make_float4(f[0], f[1], f[2], f[3]);
+                }
+                __syncthreads();
+                DTL(21);
+                for (int it = tid; it < NT * IT; it += 256) {
+                    int s = 0, rem = it;
+                    while (rem >= NP) { rem -= NP; ++s; }             // s = 2 t + j
+                    float q_ = 0.f, w_ = 0.f;
+                    du_x_item<PD>(pb, xp, lds + lXB + s * DU_DP, rem >> xp.lgP, rem & (xp.P - 1), q_, w_);
+                    lds[lXP + 2 * it] = q_; lds[lXP + 2 * it + 1] = w_;
+                }
+                __syncthreads();
+                DTL(22);
+                for (int s = wave; s < 2 * NT; s += 4) {
+                    float q_ = 0.f, w_ = 0.f;
+                    for (int a = lane; a < NP; a += 64) { q_ += lds[lXP + 2 * (s * NP + a)]; w_ += lds[lXP + 2 * (s * NP + a) + 1]; }
+                    q_ = sum64(q_); w_ = sum64(w_);
+                    if (lane == 0) {
+                        const int t = s >> 1, j = s & 1;
+                        const int off = xQ + (((par * NT + t) * DU_G + member) * 4 + 2 * j) * 4;
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 pay = {__float_as_uint(q_), __float_as_uint(w_)};
+                        if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 16);      // (the slot is reset in P3: see there)
+                    }
+                }
+            }
+            for (int t = 0; t < NT; ++t) {
+                // ================= P3: a = w + hN K1[:,H_c]^T v ; y = tanh(o) . a =================
+                const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
+                DTL(40 * t + 24);
+                u32x4 thv = du_ld(g, vb, xT + fo);
+                const int gR = xG + ((((par ^ 1) * NT + t) * DU_G + member) * DU_KBD) * 1024;
+                const f32x4 acc = du_gemm<DU_KBM, false>(g, W, 0, vb, xV + ((par * NT + t) * DU_KBM) * 1024, DUK_V, [&]() {
+                    DTL(40 * t + 25);
+                    // the partial-gradient slots of the previous evaluation: every owner has read them (it published S(e), and a V(e)
+                    // fragment exists); P3's closing vmcnt(0) then lies between this reset and the payload stored below (header, H1)
+#pragma unroll
+                    for (int mi = 0; mi < 3; ++mi) { const int mt = wave + 4 * mi; if (mt < DU_KBD) du_st_sent(g, vb, gR + mt * 1024); }
+                    // ... and the cost scalars of the previous evaluation: the owner reads them before its P1 of this evaluation
+                    if (wave == 0 && lane < 2) {
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 sen = {DU_SENT, DU_SENT};
+                        const int offr = xQ + ((((par ^ 1) * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;
+                        if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 16);
+                    }
+                });
+                DTL(40 * t + 26);
+                {
+                    int spins = 0;
+                    while (__any(du_bad(thv))) {
+                        if (du_spin(g, spins, DUK_T)) break;
+                        thv = du_ld(g, vb, xT + fo);
+                    }
+                }
+                const f32x4 th = du_f(thv);
+                float4 y;
+                y.x = th[0] * (wv[0] + hN * acc[0]); y.y = th[1] * (wv[1] + hN * acc[1]);
+                y.z = th[2] * (wv[2] + hN * acc[2]); y.w = th[3] * (wv[3] + hN * acc[3]);
+                L4[(DB_YF >> 2) + (t * 4 + wave) * 64 + lane] = y;
+                DTL(40 * t + 27);
+                __syncthreads();
+                DTL(40 * t + 28);
+                // ================= P4: partial g = K0[H_c,:]^T y for the dim tiles wave, wave+4, wave+8 =================
+                const int gP = xG + (((par * NT + t) * DU_G + member) * DU_KBD) * 1024;
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi) {
+                    const int mt = wave + 4 * mi;
+                    if (mt < DU_KBD) {
+                        f32x4 a0, a1;
+                        float4 wf[4], bf[4];
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) {
+                            wf[kb] = L4[(DB_K4 >> 2) + (mt * 4 + kb) * 64 + lane];
+                            bf[kb] = L4[(DB_YF >> 2) + (t * 4 + kb) * 64 + lane];
+                        }
+                        mfma_v0(a0, wf[0].x, bf[0].x); mfma_v0(a1, wf[0].y, bf[0].y);
+                        mfma_v(a0, wf[0].z, bf[0].z); mfma_v(a1, wf[0].w, bf[0].w);
+#pragma unroll
+                        for (int kb = 1; kb < 4; ++kb) {
+                            mfma_v(a0, wf[kb].x, bf[kb].x); mfma_v(a1, wf[kb].y, bf[kb].y);
+                            mfma_v(a0, wf[kb].z, bf[kb].z); mfma_v(a1, wf[kb].w, bf[kb].w);
+                        }
+                        DU_FENCE2(a0, a1);
+                        du_st(g, vb, gP + mt * 1024, a0 + a1);
+                    }
+                }
+                DTL(40 * t + 29);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int du_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+long duo_rows_per_launch(void) { return 32L * 16 * DU_NTMAX; }
+
+static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out) {
+    if (nTh != 2 || m != 64 * DU_G || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
+    DuoPlan dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents;
+    const long ntiles = (n + 15) / 16;
+    dp.ngroups = (int)std::min<long>(32, ntiles);
+    dp.NT = (int)((ntiles + dp.ngroups - 1) / dp.ngroups);
+    if (dp.NT > DU_NTMAX) return NOCF_E_SHAPE;
+    dp.hN = 1.0f;
+    const int ldsA = DA_T + 2 * dp.NT * DS_STRIDE, ldsB = DB_XP(dp.NT) + dp.NT * 512;
+    dp.ldsFloats = std::max(ldsA, ldsB);
+    if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
+    long o = 0;                                                                    // floats
+    dp.oPlan = o; o += 256;
+    dp.oErr = o; o += 64;                                                          // (uint index == float index)
+    dp.oXcc = o; o += 32 * 16;
+    const long nW = (long)DU_G * 4 * DU_KBM * 64, nK1 = (long)DU_G * 4 * DU_KBD * 64, nK4 = (long)DU_G * DU_KBD * 4 * 64;   // float4s
+    dp.oW2 = o / 4; o += nW * 4;
+    dp.oW3 = o / 4; o += nW * 4;
+    dp.oK1 = o / 4; o += nK1 * 4;
+    dp.oK4 = o / 4; o += nK4 * 4;
+    dp.oA = o; o += 16 * DU_DP;
+    dp.oVec = o; o += 3 * 64 * DU_G;
+    dp.oCW = o; o += DU_DP;
+    o = (o + 63) / 64 * 64;
+    dp.oX = o;
+    dp.xStride = duo_x_layout(dp.NT, nullptr);
+    *out = dp;
+    return 0;
+}
+
+static size_t duo_ws_bytes_of(const DuoPlan& dp) { return (size_t)(dp.oX + (long)dp.ngroups * dp.xStride) * sizeof(float); }
+
+int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size_t* bytes) {
+    DuoPlan dp;
+    const int rc = make_duo_plan(d, m, nTh, r, n_agents, std::min<long>(n, duo_rows_per_launch()), &dp);
+    if (rc) return rc;
+    if (bytes) *bytes = duo_ws_bytes_of(dp);
+    return 0;
+}
+
+template <int PD, bool REC>
+static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC>); }
+
+int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, float* ws, size_t ws_bytes, hipStream_t st,
+               const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
+    if (pb.kind == NOCF_PROB_QUADCOPTER || ra_in.zFull) return 1;
+    const long chunk = duo_rows_per_launch();
+    DuoPlan dp0;
+    if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(ra_in.n, chunk), &dp0) != 0) return 1;
+    if (ws_bytes < duo_ws_bytes_of(dp0)) return 1;
+    const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
+    const bool rec = ra_in.sAll != nullptr;
+    const void* fk = c2 ? (rec ? duo_fn<2, true>() : duo_fn<2, false>()) : (rec ? duo_fn<3, true>() : duo_fn<3, false>());
+    // residency: all 16 x ngroups workgroups spin on each other, so every one of them must be resident at once: two per CU
+    // (256 registers per lane, <= 80 KB LDS).  The grid is checked against what the runtime says fits; the stream must be
+    // otherwise idle (a concurrent kernel on another stream can take the CUs: the bounded polls then time out and the host raises).
+    int dev = 0, cus = 0, perCU = 0;
+    if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) return 1;
+    const size_t ldsBytes0 = (size_t)dp0.ldsFloats * 4;
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024));
+    if (e) return (int)e;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fk, 256, ldsBytes0) != hipSuccess) return 1;
+    const int grid0 = 128 * ((dp0.ngroups + 7) / 8);
+    if ((long)perCU * cus < grid0) {
+        if (debug) fprintf(stderr, "[nocf] duo kernel: grid %d does not fit (%d workgroups per CU x %d CUs)\n", grid0, perCU, cus);
+        return 1;
+    }
+    DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
+    for (long r0 = 0; r0 < ra_in.n; r0 += chunk) {
+        const long cn = std::min<long>(chunk, ra_in.n - r0);
+        DuoPlan dp;
+        int rc = make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cn, &dp);
+        if (rc) return rc;
+        dp.cb = phi->cb;
+        dp.fast = du_env_int("NOCF_DUO_FAST", 1);
+        dp.mapmode = du_env_int("NOCF_DUO_MAP", 0);
+        dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
+        hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws);     // (every chunk: the plan record changes with the chunk's rows)
+        if (r0 == 0) { e = hipMemsetAsync(ws + dp.oErr, 0, 64 * 4, st); if (e) return (int)e; }
+        e = hipMemsetAsync(ws + dp.oXcc, 0, 32 * 16 * 4, st); if (e) return (int)e;
+        e = hipMemsetAsync(ws + dp.oX, 0xFF, (size_t)dp.ngroups * dp.xStride * 4, st);            // every exchange word starts as the sentinel
+        if (e) return (int)e;
+        RollArgs ra = ra_in;
+        ra.x = ra_in.x + r0 * phi->d; ra.n = cn;
+        if (ra.z_out) ra.z_out = ra_in.z_out + r0 * (phi->d + 4);
+        if (ra.persample) ra.persample = ra_in.persample + r0 * 7;
+        DuoRun rr{r0, ra_in.n};
+        const DuoPlan* dpp = reinterpret_cast<const DuoPlan*>(ws + dp.oPlan);
+        const size_t ldsBytes = (size_t)dp.ldsFloats * 4;
+        if (debug) fprintf(stderr, "[nocf] duo kernel: rows %ld..%ld, %d groups x 16 workgroups, %d tile(s) of 16 samples, LDS %zu B/workgroup, %d workgroups/CU fit\n",
+                           r0, r0 + cn, dp.ngroups, dp.NT, ldsBytes, perCU);
+        void* args[] = {(void*)&dpp, (void*)&pb, (void*)&ws, (void*)&ra, (void*)&rr};
+        if (ev0 && r0 == 0) (void)hipEventRecord(ev0, st);
+        e = hipLaunchKernel(fk, dim3(128 * ((dp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st);
+        if (e) return (int)e;
+        if (ev1 && r0 + chunk >= ra_in.n) (void)hipEventRecord(ev1, st);
+    }
+    *errp = reinterpret_cast<const unsigned*>(ws) + dp0.oErr;
+    return 0;
+}

@@ -28,12 +28,10 @@
 #include <vector>
 #include "nocf.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// All LDS lives in one dynamic array that every device function names directly (never through a
-// stored pointer), so each access is a ds_* instruction, not a flat one.
-extern __shared__ __attribute__((aligned(16))) float lds[];
+#include "nocf_dev.h"
+#ifndef NOCF_JIT_ONLY
+#include "nocf_duo.h"
+#endif
 
 #ifndef NOCF_MAXTHREADS
 #define NOCF_MAXTHREADS 512   // waves per workgroup * 64; 256 gives each wave the whole 512-register file
@@ -41,7 +39,6 @@ extern __shared__ __attribute__((aligned(16))) float lds[];
 #define HALF 8               // k-quads (4 k-steps each) per third of the weight ring
 #define MAX_SK 8             // max split-K factor of a GEMM phase
 #define MAX_NTH 12
-#define ZQLD 16              // row stride of the z = A s rows (r <= 16)
 
 // ------------------------------------------------------------------------------------------
 // plan: shapes, packed-image offsets, LDS carve.  Built on the host, passed by value.
@@ -227,16 +224,6 @@ static bool plan_is(const DevPlan& run) {
     return memcmp(&a, &b, sizeof(DevPlan)) == 0;
 }
 
-struct DevProb {
-    int kind, obstacle, nAgents, training, agentDim;
-    double r, alphQ, alphW, mass, grav;
-    const float* xtarget;
-};
-
-struct DevPhi {
-    const float *K0, *b0, *K, *b, *w, *A, *cw;
-    const float* cbp;                // device address of c.bias, or null (then the plan carries the host value)
-};
 
 // ------------------------------------------------------------------------------------------
 // weight packing: image[cb][kq][lane] = float4 of B[k = 4kq..4kq+3][col = 64cb + lane]
@@ -327,60 +314,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float sigma_act(float o) {      // src/Phi.py:8-9
-    const float ao = fabsf(o);
-    return ao + logf(1.f + expf(-2.f * ao));
-}
 
-// sigma(o) and tanh(o) from one exponential: e = exp(-2|o|) in (0,1];
-//   sigma = |o| + log(1+e)           (the reference's own overflow-safe form, src/Phi.py:8-9)
-//   tanh  = sign(o) (1-e)/(1+e)      (absolute error <= ~1e-7, like any fp32 rounding of an O(1) value)
-// hardware v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp) instead of the ~60-instruction libm calls.
-__device__ __forceinline__ void act_pair(float o, float& sig, float& th) {
-    const float ao = fabsf(o);
-    const float e = __builtin_amdgcn_exp2f(ao * -2.885390081777927f);       // exp(-2|o|) = 2^(-2 log2(e) |o|)
-    const float p = 1.f + e;
-    sig = ao + 0.6931471805599453f * __builtin_amdgcn_logf(p);             // v_log_f32 is log2
-    th = copysignf((1.f - e) * __builtin_amdgcn_rcpf(p), o);
-}
-
-__device__ __forceinline__ float tanh_fast(float o) {
-    const float e = __builtin_amdgcn_exp2f(fabsf(o) * -2.885390081777927f);
-    return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), o);
-}
-
-// ------------------------------------------------------------------------------------------
-// lane reductions on the DPP path (VALU operand swizzles, a few cycles each) instead of __shfl_xor, which hipcc turns
-// into ds_bpermute_b32: an LDS round trip (>100 cycles) per step of a dependent chain.
-//   quad_perm [1,0,3,2] = lane^1, [2,3,0,1] = lane^2, row_half_mirror = 7-i within 8 lanes, row_mirror = 15-i within 16
-// After k steps every lane of an aligned 2^k group holds the group's sum (fixed order: deterministic).
-// ------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_peer(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float sum2(float v) { return v + dpp_peer<0xB1>(v); }
-__device__ __forceinline__ float sum4(float v) { v = sum2(v); return v + dpp_peer<0x4E>(v); }
-__device__ __forceinline__ float sum8(float v) { v = sum4(v); return v + dpp_peer<0x141>(v); }
-__device__ __forceinline__ float sum16(float v) { v = sum8(v); return v + dpp_peer<0x140>(v); }
-// all 64 lanes (every lane must be active): the four row totals meet through scalar registers
-__device__ __forceinline__ float sum64(float v) {
-    v = sum16(v);
-    const int b = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
-    return (r0 + r1) + (r2 + r3);
-}
-// aligned groups of seg = 2, 4, ..., 64 lanes
-__device__ __forceinline__ float sum_seg(float v, int seg) {
-    if (seg >= 64) return sum64(v);
-    if (seg >= 2) v += dpp_peer<0xB1>(v);
-    if (seg >= 4) v += dpp_peer<0x4E>(v);
-    if (seg >= 8) v += dpp_peer<0x141>(v);
-    if (seg >= 16) v += dpp_peer<0x140>(v);
-    if (seg >= 32) v += __shfl_xor(v, 16);            // (no 32-lane DPP pattern on gfx9: one crossbar step)
-    return v;
-}
 
 struct Ctx {
     const float* ws;
@@ -823,60 +757,6 @@ __device__ void phi_eval(const Ctx& c, const DevPlan& pl, bool need_value, Ring&
 // ------------------------------------------------------------------------------------------
 // problem physics.  Cross2D.py:69-162, SwarmTraj.py:68-164, Quadcopter.py:65-113, utils.py:70-86.
 // ------------------------------------------------------------------------------------------
-#define TWO_PI_D 6.283185307179586
-
-__device__ __forceinline__ float gauss2(float x0, float x1, float m0, float m1, float cov, float denom) {
-    const float e0 = x0 - m0, e1 = x1 - m1;
-    return expf(-0.5f * ((e0 * e0) / cov + (e1 * e1) / cov)) / denom;
-}
-
-__device__ __forceinline__ float obstacle_cross2d(const DevProb& pb, float x0, float x1) {
-    if (pb.obstacle == NOCF_OBS_SOFTCORRIDOR) {
-        const float cov = 0.2f;
-        const float denom = (float)TWO_PI_D * sqrtf(cov * cov);
-        return ((gauss2(x0, x1, -2.5f, 0.f, cov, denom) + gauss2(x0, x1, 2.5f, 0.f, cov, denom))
-                + gauss2(x0, x1, -1.5f, 0.f, cov, denom)) + gauss2(x0, x1, 1.5f, 0.f, cov, denom);
-    }
-    if (pb.obstacle == NOCF_OBS_HARDCORRIDOR) {
-        const float denom = (float)TWO_PI_D * 1.0f;
-        const float n1 = sqrtf(x0 * x0 + (x1 - 4.f) * (x1 - 4.f));
-        const float n2 = sqrtf(x0 * x0 + (x1 + 3.5f) * (x1 + 3.5f));
-        if (pb.training) {
-            const float thr = (float)(2.0 + pb.r);
-            if ((n1 < thr) || (n2 < thr))
-                return gauss2(x0, x1, 0.f, 4.f, 1.f, denom) + gauss2(x0, x1, 0.f, -3.5f, 1.f, denom);
-            return 0.f;
-        }
-        return ((n1 < 2.0f) || (n2 < 2.0f)) ? 1.f : 0.f;     // eval: the mask itself is summed (a count)
-    }
-    return 0.f;
-}
-
-__device__ __forceinline__ float obstacle_swarm(const DevProb& pb, float x0, float x1, float x2) {
-    if (pb.obstacle != NOCF_OBS_BLOCKS) return 0.f;
-    if (pb.training) {
-        const double r = pb.r;
-        const bool in1 = (x0 < (float)(2.0 + r)) && (x0 > (float)(-2.0 - r)) && (x1 < (float)(0.5 + r)) &&
-                         (x1 > (float)(-0.5 - r)) && (x2 < (float)(7.0 + r));
-        const bool in2 = (x0 < (float)(4.0 + r)) && (x0 > (float)(2.0 - r)) && (x1 < (float)(1.0 + r)) &&
-                         (x1 > (float)(-1.0 - r)) && (x2 < (float)(4.0 + r));
-        if (!(in1 || in2)) return 0.f;
-        const float c15 = (float)15.749609945722419;          // (2 pi)^1.5
-        const float den1 = c15 * sqrtf(243.f), den2 = c15 * sqrtf(81.f);
-        float e0 = x0, e1 = x1, e2 = x2 - 2.f;
-        const float q1 = expf(-0.5f * (((e0 * e0) / 9.f + (e1 * e1) / 3.f) + (e2 * e2) / 9.f)) / den1;
-        e0 = x0 - 2.5f;
-        const float q2 = expf(-0.5f * (((e0 * e0) / 9.f + (e1 * e1) / 3.f) + (e2 * e2) / 3.f)) / den2;
-        return (q1 + q2) + 999.f;
-    }
-    const bool in1 = (x0 < 2.0f) && (x0 > -2.0f) && (x1 < 0.5f) && (x1 > -0.5f) && (x2 < 7.0f);
-    const bool in2 = (x0 < 4.0f) && (x0 > 2.0f) && (x1 < 1.0f) && (x1 > -1.0f) && (x2 < 4.0f);
-    return (in1 || in2) ? 1.f : 0.f;
-}
-
-__device__ __forceinline__ bool want_W(const DevProb& pb) {
-    return (pb.kind == NOCF_PROB_QUADCOPTER) ? (pb.alphW > 0.0) : (pb.alphW != 0.0);
-}
 
 // Interaction sum of one sample by cyclic pairing: agent a meets its partners (a+j) mod N, j = 1..(N-1)/2 (for
 // even N the opposite agent j = N/2 as well, counted from the lower half only), so every unordered pair appears
@@ -1114,14 +994,6 @@ __device__ void ctrl_write(const Ctx& c, const DevPlan& pl, const DevProb& pb, f
 // ------------------------------------------------------------------------------------------
 // the rollout kernel: src/OCflow.py:7-95 for T samples per workgroup
 // ------------------------------------------------------------------------------------------
-struct RollArgs {
-    const float* x; long n;
-    double t0, t1, h; int nt, stepper;
-    float a0;
-    float* z_out; float* persample; float* zFull; float* ctrlFull; int cdim;
-    unsigned long long* stamps;
-    float* sAll;                     // training: stage inputs s=[x,t] of every RK evaluation, [nt*nstage][n][d+1]
-};
 
 template <int S>
 __device__ __forceinline__ void rollout_body(const DevPlan& pl, const DevPlan* __restrict__ plp, const DevProb& pb,
@@ -2038,6 +1910,10 @@ size_t nocf_rollout_workspace_bytes(int32_t d, int32_t m, int32_t nTh, int64_t n
     if (n > 0 && make_slab_plan(pl, 1, std::min<long>(n, 1024), &sp) == 0) b = std::max(b, slab_ws_bytes(sp));
     MonoPlan mpl;
     if (make_mono_plan(pl, 1, &mpl) == 0) b = std::max(b, mono_ws_bytes(mpl));
+#ifndef NOCF_JIT_ONLY
+    size_t db = 0;
+    if (n > 0 && duo_workspace_bytes(d, m, nTh, r, 1, n, &db) == 0) b = std::max(b, db);
+#endif
     return b;
 }
 
@@ -2107,6 +1983,28 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         }
         return 0;
     }
+#ifndef NOCF_JIT_ONLY
+    // split-role weight-stationary kernel (nocf_duo.hip): wide two-layer networks (m = 512) on point-agent problems, any batch
+    // size (chunks of 2048 rows), evaluation and the recording forward of training
+    if (env_int("NOCF_DUO", 1) != 0 && !(env_int("NOCF_GROUP", 0) != 0) && !(env_int("NOCF_SLAB", 1) >= 2)) {
+        if (g_prof_on) {
+            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+        }
+        rc = duo_launch(phi, pb, ra, ws, workspace_bytes, st, &errp, env_int("NOCF_DEBUG", 0), g_prof_on ? ev0 : nullptr, g_prof_on ? ev1 : nullptr);
+        if (rc == 0) {
+            g_last_kernel = "rollout_duo_kernel";
+            if (g_prof_on) g_prof_events.emplace_back(ev0, ev1);
+            if (cost_sums) {
+                hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
+                e = hipGetLastError();
+                if (e) return (int)e;
+            }
+            return 0;
+        }
+        if (g_prof_on) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; }
+        if (rc != 1) return rc;
+    }
+#endif
     rc = pack_weights(pl, phi, ws, st);
     if (rc) return rc;
     const DevPlan* plp = reinterpret_cast<const DevPlan*>(ws + pl.oPlan);

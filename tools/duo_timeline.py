@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Diagnostic (-DNOCF_STAMPS build, tools/build_stamps.sh): per-wave timeline of ONE evaluation of group 0 / member 0 of the
+split-role kernel (nocf_duo.hip), both role workgroups, in shader cycles relative to the earliest stamp.
+   python tools/duo_timeline.py [n]"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ.setdefault("NOCF_LIB_PATH", os.path.join(REPO, "neuraloc_amd", "csrc", "libnocf_stamps.so"))
+
+import torch                                   # noqa: E402
+import bench                                   # noqa: E402
+import neuraloc_amd as na                      # noqa: E402
+from neuraloc_amd import _lib                  # noqa: E402
+
+A_PT = {0: "own: entry", 1: "own: partial gradients valid", 2: "own: RK done, S stored", 3: "own: costs done",
+        4: "P1: entry", 5: "P1: first S fragment valid", 6: "P1: gemm done", 7: "P1: epilogue + stores",
+        10: "P2: entry", 11: "P2: first U fragment valid", 12: "P2: gemm done", 13: "P2: V stored"}
+B_PT = {24: "P3: entry", 25: "P3: first V fragment valid", 26: "P3: gemm done", 27: "P3: th valid, y written",
+        28: "P3: barrier passed", 29: "P4: done (G stored)"}
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    meta, sd, xtarget, xInit = bench.load_workload("swarm50")
+    dev = torch.device("cuda:0")
+    net, prob = bench.build_objects(meta, sd, xtarget, dev)
+    x = bench.make_states(meta, xInit, n, 200).to(dev)
+    buf = torch.zeros(8 * 128 + 4096, dtype=torch.int64, device=dev)
+    assert _lib.lib().nocf_debug_set_stamp_buffer(buf.data_ptr()) == 0, "this is not the NOCF_STAMPS build"
+    with torch.no_grad():
+        for _ in range(2):
+            buf.zero_()
+            na.OCflow(x, net, prob, [0.0, 1.0], meta["nt"], "rk4", meta["alph"])
+        torch.cuda.synchronize()
+    print("kernel:", _lib.lib().nocf_last_rollout_kernel().decode())
+    tl = buf[:8 * 128].view(2, 4, 128).cpu()
+    t0 = int(tl[tl > 0].min())
+    nt_tiles = max(1, min(4, (((n + 15) // 16) + 31) // 32))
+    rows = []
+    for t in range(nt_tiles):
+        for i, name in A_PT.items():
+            rows.append(("A", 40 * t + i, f"A tile {t}: {name}"))
+    rows.append(("A", 8, "A: z / A^T z start"))
+    rows.append(("A", 9, "A: z / A^T z done"))
+    rows += [("B", 20, "B: evaluation entry"), ("B", 21, "B: own states loaded + barrier"), ("B", 22, "B: pair sums + barrier")]
+    for t in range(nt_tiles):
+        for i, name in B_PT.items():
+            rows.append(("B", 40 * t + i, f"B tile {t}: {name}"))
+    out = []
+    for role, pid, name in rows:
+        r = 0 if role == "A" else 1
+        vals = [int(tl[r, w, pid]) - t0 if int(tl[r, w, pid]) > 0 else -1 for w in range(4)]
+        if max(vals) < 0:
+            continue
+        out.append((min(v for v in vals if v >= 0), name, vals))
+    out.sort()
+    print(f"n={n}: one evaluation of group 0 / member 0 (cycles since the earliest stamp); -1 = this wave has no such point")
+    print(f"{'point':46s}" + "".join(f"   wave{w}" for w in range(4)))
+    for _, name, vals in out:
+        print(f"{name:46s}" + "".join(f"{v:8d}" for v in vals))
+
+
+if __name__ == "__main__":
+    main()
