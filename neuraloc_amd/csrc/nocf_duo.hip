@@ -55,14 +55,16 @@
 #define DU_R 8                     // B fragments in flight per wave (1 KiB each)
 #define DU_NTMAX 4                 // tiles of 16 samples per group (LDS carve of role A)
 #define DU_SENT 0xFFFFFFFFu
+#define DU_PREFETCH_G 0              // 1: request the next owner step's partial gradients in front of P2 (32 more live registers: it spills -- 8.4 vs 5.9 ms; kept for a build with more register room)
 enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P = 7, DUK_XCC = 8 };
 
-// LDS carve (float offsets).  Role A: P1's A-operand image, A, c, the member's slices of b0 / b1 / w, per-tile owner state.
-#define DA_K1 0                                    // [4 waves][10 kb][64 lanes][4]
-#define DA_A (DA_K1 + 4 * DU_KBD * 256)            // [16][160], rows >= r and columns >= d+1 are 0
+// LDS carve (float offsets).  Role A: A, c, the member's slices of b0 / b1 / w, the staged S and U tiles, per-sample owner state.
+#define DA_A 0                                     // [16][160], rows >= r and columns >= d+1 are 0
 #define DA_CW (DA_A + 16 * DU_DP)                  // [160]
 #define DA_VEC (DA_CW + DU_DP)                     // b0 | b1 | w, 64 each
-#define DA_T (DA_VEC + 192)                        // per own sample (2 per tile): the block below
+#define DA_SF (DA_VEC + 192)                       // staged stage-state tile: [10 kb][64 lanes][4]
+#define DA_UF (DA_SF + DU_KBD * 256)               // staged u0 tile: [32 kb][64][4]
+#define DA_T (DA_UF + DU_KBM * 256)                // per own sample (2 per tile): the block below
 #define DS_XS 0                                    // [160] stage state (entry d = time)
 #define DS_Z0 160                                  // [160] state at the start of the step
 #define DS_ZA 320                                  // [160] RK accumulator
@@ -71,17 +73,20 @@ enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P =
 #define DS_CZ 656                                  // [8]   cost integrals L, HJt, Q, W: value, RK accumulator
 #define DS_PHX 664                                 // [2]   c.s and 1/2 |A s|^2 (final time)
 #define DS_STRIDE 672
-// Role B: P4's A-operand image, w slice, the y fragments, own states, cost-pass partials
+// Role B: P4's A-operand image, w slice, the staged v tile, the y fragments, the own states of the current tile, cost partials
 #define DB_K4 0                                    // [10 mt][4 kb][64][4]
 #define DB_VEC (DB_K4 + DU_KBD * 4 * 256)          // w, 64
-#define DB_YF (DB_VEC + 64)                        // [NT][4 waves][64][4]
-#define DB_XB(NT) (DB_YF + (NT) * 1024)            // [NT][2][160]
-#define DB_XP(NT) (DB_XB(NT) + (NT) * 320)         // [NT][<=256 items][2]
+#define DB_VF (DB_VEC + 64)                        // staged v tile: [32 kb][64][4]
+#define DB_YF (DB_VF + DU_KBM * 256)               // [4 waves][64][4]
+#define DB_XB (DB_YF + 1024)                       // [2][160]
+#define DB_XP (DB_XB + 2 * DU_DP)                  // [4 waves][2]
+#define DB_END (DB_XP + 16)
 
 struct DuoPlan {
     int d, D1, r, nAg, NT, ngroups, spin_max, fast;
     float hN, cb;
     int mapmode, ldsFloats;
+    int dbg, pad_;                 // (spare)
     long oW2, oW3, oK1, oK4;        // float4 offsets of the images in the workspace
     long oA, oVec, oCW;             // float offsets: A [16][160], b0 | b1 | w [3][512], c.weight [160]
     long oPlan, oErr, oXcc, oX, xStride;
@@ -218,58 +223,70 @@ __device__ __forceinline__ bool du_spin(DCtx& g, int& spins, unsigned what) {
     return false;
 }
 
-// acc = sum over NKB k-blocks of (A fragment) x (B fragment kb of the exchange buffer at byte offset sbyte, streamed from L2).
-// A fragments: AccVGPRs W[kb] (LDSA false) or LDS float4s at index a4 + kb*64 (LDSA true).  Two accumulation chains (a
-// dependent v_mfma_f32_16x16x4_f32 may issue 40 cycles behind its producer; the chains alternate at 32).  A fragment that
-// still shows a sentinel word is polled alone, then the rest of the ring is requested again (the requests behind a stale
-// fragment are most likely stale too).  after_first() runs once the first fragment has been validated.
-template <int NKB, bool LDSA, class F0>
-__device__ __forceinline__ f32x4 du_gemm(DCtx& g, const f32x4 (&W)[DU_KBM], int a4, int vbyte, int sbyte, unsigned what, F0&& after_first) {
-    u32x4 ring[DU_R];
-#pragma unroll
-    for (int i = 0; i < DU_R; ++i) if (i < NKB) ring[i] = du_ld(g, vbyte, sbyte + i * 1024);
-    const float4* L4 = reinterpret_cast<const float4*>(lds);
-    float4 ar[4];
-    if (LDSA) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ar[i] = L4[a4 + (i < NKB ? i : 0) * 64];
-    }
-    f32x4 a0, a1;
+// My share of an exchange buffer of NF fragments -> LDS: wave w takes the fragments f = w, w+4, ... (NFW = ceil(NF / 4) of them,
+// all requested together: one L2 round trip), repeats the requests while any of them shows a sentinel word (the data IS the
+// signal), then writes them to the staging buffer at LDS float4 index l4.  The four waves of a workgroup share the staged tile:
+// a fragment crosses L2 -> CU once per workgroup (streamed by every wave for itself -- the first form of this kernel -- the
+// 32 waves of a group pulled 4 MB per GEMM and XCD through L2 and every stream ran at the L2 latency: 190 cycles per k-block).
+template <int NF>
+__device__ __forceinline__ void du_gather(DCtx& g, int wave, int lane, int sbyte, int l4, unsigned what) {
+    constexpr int NFW = (NF + 3) / 4;
+    u32x4 v[NFW];
     int spins = 0;
+    while (true) {
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) v[u] = du_ld(g, lane * 16, sbyte + (wave + 4 * u) * 1024);
+#pragma unroll
+        for (int u = 0; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) bad |= du_bad(v[u]);
+        if (!__any(bad)) break;
+        if (du_spin(g, spins, what)) break;
+    }
+    float4* L4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int u = 0; u < NFW; ++u)
+        if (NF % 4 == 0 || wave + 4 * u < NF) { const f32x4 f = du_f(v[u]); L4[l4 + (wave + 4 * u) * 64 + lane] = make_float4(f[0], f[1], f[2], f[3]); }
+}
+
+// acc = sum over NKB k-blocks of W[kb] (A operand: AccVGPRs if ACC, else VGPRs) x the staged fragments at LDS float4 index b4 + kb*64 (B operand).
+// Two accumulation chains (a dependent v_mfma_f32_16x16x4_f32 may issue 40 cycles behind its producer; the chains alternate
+// at 32), B fragments read 3 k-blocks (12 MFMAs = 384 cycles) ahead of their use.
+template <int NKB, bool ACC>
+__device__ __forceinline__ f32x4 du_gemm_lds(const f32x4 (&W)[NKB], int b4) {
+    const float4* L4 = reinterpret_cast<const float4*>(lds);
+    float4 ring[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ring[i] = L4[b4 + (i < NKB ? i : 0) * 64];
+    f32x4 a0, a1;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        if (LDSA && kb + 3 < NKB) ar[(kb + 3) & 3] = L4[a4 + (kb + 3) * 64];
-        if (__builtin_expect(__any(du_bad(ring[kb % DU_R])), 0)) {
-            while (true) {
-                if (du_spin(g, spins, what)) break;
-                ring[kb % DU_R] = du_ld(g, vbyte, sbyte + kb * 1024);
-                if (!__any(du_bad(ring[kb % DU_R]))) break;
-            }
-#pragma unroll
-            for (int i = 1; i < DU_R; ++i) if (kb + i < NKB) ring[(kb + i) % DU_R] = du_ld(g, vbyte, sbyte + (kb + i) * 1024);
-        }
-        const f32x4 b = du_f(ring[kb % DU_R]);
-        if (LDSA) {
-            const float4 w = ar[kb & 3];
-            if (kb == 0) { mfma_v0(a0, w.x, b[0]); mfma_v0(a1, w.y, b[1]); after_first(); }
-            else { mfma_v(a0, w.x, b[0]); mfma_v(a1, w.y, b[1]); }
-            mfma_v(a0, w.z, b[2]); mfma_v(a1, w.w, b[3]);
+        if (kb + 3 < NKB) ring[(kb + 3) & 3] = L4[b4 + (kb + 3) * 64];
+        const float4 b = ring[kb & 3];
+        if (ACC) {
+            if (kb == 0) { mfma_a0(a0, W[0][0], b.x); mfma_a0(a1, W[0][1], b.y); }
+            else { mfma_a(a0, W[kb][0], b.x); mfma_a(a1, W[kb][1], b.y); }
+            mfma_a(a0, W[kb][2], b.z); mfma_a(a1, W[kb][3], b.w);
         } else {
-            if (kb == 0) { mfma_a0(a0, W[0][0], b[0]); mfma_a0(a1, W[0][1], b[1]); after_first(); }
-            else { mfma_a(a0, W[kb][0], b[0]); mfma_a(a1, W[kb][1], b[1]); }
-            mfma_a(a0, W[kb][2], b[2]); mfma_a(a1, W[kb][3], b[3]);
+            if (kb == 0) { mfma_v0(a0, W[0][0], b.x); mfma_v0(a1, W[0][1], b.y); }
+            else { mfma_v(a0, W[kb][0], b.x); mfma_v(a1, W[kb][1], b.y); }
+            mfma_v(a0, W[kb][2], b.z); mfma_v(a1, W[kb][3], b.w);
         }
-        if (kb + DU_R < NKB) ring[kb % DU_R] = du_ld(g, vbyte, sbyte + (kb + DU_R) * 1024);
     }
     DU_FENCE2(a0, a1);
     return a0 + a1;
 }
-struct DuNop { __device__ __forceinline__ void operator()() const {} };
 
 // Diagnostic build only (-DNOCF_STAMPS): per-wave shader-clock timeline of ONE evaluation of group 0 / member 0 (both roles):
 // tools/duo_timeline.py.  The production library contains no stamp.
 #ifdef NOCF_STAMPS
-#define DTL(id) do { if (tlp && lane == 0) tlp[id] = clock64(); } while (0)
+// (100 MHz, one clock for the whole chip: s_memtime differs between workgroups.  The asm is volatile with a memory clobber so that
+// a stamp stays where it is written relative to loads, stores and other stamps.)
+__device__ __forceinline__ unsigned long long du_now() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define DTL(id) do { if (tlp) { const unsigned long long t_ = du_now(); if (lane == 0) tlp[id] = t_; } } while (0)
 #else
 #define DTL(id) do { } while (0)
 #endif
@@ -279,11 +296,10 @@ __device__ __forceinline__ float du_pair_term(float s2, float thr, float thr2, f
     // branch-free: v_sqrt_f32 / v_exp_f32 (1 ulp each); the mask is the reference's `dist < thr`, entries equal to 1 are dropped
     const float dist = __builtin_amdgcn_sqrtf(s2);
     const float e = __builtin_amdgcn_exp2f((dist * dist) * nden_l2e);
-    return (s2 < thr2 && dist < thr && e != 1.f) ? e : 0.f;
+    const bool keep = (s2 < thr2) & (dist < thr) & (e != 1.f);
+    return keep ? e : 0.f;
 }
-// Thread item (sample, agent a, part): the agent meets the partners (a + j) mod N, j = 1..J = (N-1)/2 (every unordered pair once),
-// for even N also the opposite agent j = N/2 from the lower half; the P parts split that range.  Part 0 adds the agent's obstacle term.
-struct DXPar { float thr, thr2, nden_l2e, den, thr_pair2; int N, J, JJ, P, lgP, Jp; bool obs, wantW; };
+struct DXPar { float thr, thr2, nden_l2e, den, thr_pair2; int N, J, JJ, Jh; bool obs, wantW; };
 __device__ __forceinline__ DXPar du_x_params(const DevProb& pb, int PD) {
     DXPar xp;
     xp.N = pb.nAgents;
@@ -295,56 +311,61 @@ __device__ __forceinline__ DXPar du_x_params(const DevProb& pb, int PD) {
     xp.thr2 = xp.thr * xp.thr * 1.000002f;
     xp.nden_l2e = -1.4426950408889634f / xp.den;
     xp.thr_pair2 = (float)((pb.training ? 2.2 : 2.0) * pb.r);        // the two-agent form of calcW
-    xp.J = (xp.N - 1) >> 1;
-    xp.JJ = (xp.wantW && xp.N > 2) ? xp.J + (((xp.N & 1) == 0) ? 1 : 0) : 0;
-    xp.P = 1; xp.lgP = 0;
-    while (xp.P < 4 && 2 * xp.N * xp.P * 2 <= 256) { xp.P *= 2; ++xp.lgP; }      // items per tile = 2 samples x N x P <= 256
-    xp.Jp = (xp.JJ + xp.P - 1) / xp.P;
+    xp.J = (xp.N - 1) >> 1;                                           // partners every agent meets: (a + j) mod N, j = 1..J
+    xp.JJ = (xp.wantW && xp.N > 2) ? xp.J + (((xp.N & 1) == 0) ? 1 : 0) : 0;   // even N: also the opposite agent j = N/2, from the lower half only
+    xp.Jh = (xp.JJ + 1) >> 1;                                         // the two halves of the partner range: [1, Jh], (Jh, JJ]
     return xp;
 }
+// One wave = one own sample x one half of the partner range; lane a < N is agent a (its position stays in registers), the partners'
+// positions come from the sample's LDS row through a pointer that advances one agent per partner (consecutive lanes read consecutive
+// agents: conflict-free; no per-partner index arithmetic).  Half 0 adds the obstacle terms.  Straight-line selects, no per-pair
+// branches; every unordered pair is counted once.  Returns this lane's partial sums.
 template <int PD>
-__device__ __forceinline__ void du_x_item(const DevProb& pb, const DXPar& xp, const float* __restrict__ x /* LDS row of the sample */, int a, int part,
+__device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, int xoff /* LDS float index of the sample's row */, int lane, int half,
                                           float& qacc, float& wacc) {
     const int N = xp.N;
+    const bool act = lane < N;
+    const int a = act ? lane : 0;
     float xa[PD];
 #pragma unroll
-    for (int k = 0; k < PD; ++k) xa[k] = x[PD * a + k];
-    if (part == 0 && xp.obs) qacc += (PD == 2) ? obstacle_cross2d(pb, xa[0], xa[1]) : obstacle_swarm(pb, xa[0], xa[1], xa[PD - 1]);
+    for (int k = 0; k < PD; ++k) xa[k] = lds[xoff + PD * a + k];
+    if (half == 0 && xp.obs) {
+        const float ob = (PD == 2) ? obstacle_cross2d(pb, xa[0], xa[1]) : obstacle_swarm(pb, xa[0], xa[1], xa[PD - 1]);
+        qacc += act ? ob : 0.f;
+    }
     if (!xp.wantW) return;
     if (N == 2) {
-        if (a == 0 && part == 0) {
+        if (half == 0 && lane == 0) {
             float s2 = 0.f;
-            for (int k = 0; k < PD; ++k) { const float e = x[k] - x[PD + k]; s2 += e * e; }
+            for (int k = 0; k < PD; ++k) { const float e = lds[xoff + k] - lds[xoff + PD + k]; s2 += e * e; }
             const float dist = sqrtf(s2);
             if (dist < xp.thr_pair2) wacc += expf(-(dist * dist) / xp.den);
         }
         return;
     }
-    const int jlo = 1 + part * xp.Jp;
-    int jhi = jlo + xp.Jp; if (jhi > xp.JJ + 1) jhi = xp.JJ + 1;                   // partners [jlo, jhi)
-    if (jhi == xp.JJ + 1 && xp.JJ > xp.J && a >= (N >> 1)) --jhi;                   // the opposite agent counts from the lower half only
-    int b = a + jlo; while (b >= N) b -= N;
-    const float* xbp = x + PD * b;
-    const float* xend = x + PD * N;
+    const int jlo = half ? xp.Jh + 1 : 1, jhi = half ? xp.JJ : xp.Jh;           // partners jlo..jhi (inclusive)
+    const bool lowhalf = a < (N >> 1);                                          // the opposite agent (even N) counts from the lower half only
+    int b = a + jlo; b -= (b >= N) ? N : 0;
+    int pp = xoff + PD * b;
+    const int pend = xoff + PD * N;
     constexpr int XW = 5;                                   // partners per round (their LDS reads are in flight together)
-    for (int j = jlo; j < jhi; j += XW) {
-        float xb[XW][PD];
-#pragma unroll
-        for (int u = 0; u < XW; ++u) {
-#pragma unroll
-            for (int k = 0; k < PD; ++k) xb[u][k] = xbp[k];
-            xbp += PD; if (xbp >= xend) xbp -= PD * N;
-        }
+    for (int j = jlo; j <= jhi; j += XW) {
         float s2[XW];
-        bool near = false;
 #pragma unroll
         for (int u = 0; u < XW; ++u) {
+            float xb[PD];
+#pragma unroll
+            for (int k = 0; k < PD; ++k) xb[k] = lds[pp + k];
+            pp += PD; pp -= (pp >= pend) ? PD * N : 0;
             float a2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < PD; ++k) { const float e = xa[k] - xb[u][k]; a2 += e * e; }
-            s2[u] = (j + u < jhi) ? a2 : 3.0e38f;
-            near |= s2[u] < xp.thr2;
+            for (int k = 0; k < PD; ++k) { const float e = xa[k] - xb[k]; a2 += e * e; }
+            const bool valid = act & (j + u <= jhi) & ((j + u <= xp.J) | lowhalf);
+            s2[u] = valid ? a2 : 3.0e38f;
         }
+        bool near = false;
+#pragma unroll
+        for (int u = 0; u < XW; ++u) near |= s2[u] < xp.thr2;
         // pairs within the interaction radius are rare: the square roots and exponentials are skipped for the whole wave unless
         // one of its pairs of this round is near -- every skipped term is exactly 0
         if (__any(near)) {
@@ -380,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     const int tid = threadIdx.x, lane = tid & 63, slot = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int NT = dp.NT; DU_PIN(NT);
-    const int d = dp.d, D1 = dp.D1;
+    const int d = dp.d;
     const float hN = dp.hN;
     DXOff xo;
     (void)duo_x_layout(NT, &xo);
@@ -396,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 #ifdef NOCF_STAMPS
     unsigned long long* tlp = nullptr;
     const int e_probe = (ra.nt / 2) * ((ra.stepper == NOCF_RK4) ? 4 : 1) + 2;
-#define DTL_EPOCH(e_) tlp = (ra.stamps && group == 0 && member == 0 && (e_) == e_probe) ? ra.stamps + (role * 4 + wave) * 128 : nullptr
+#define DTL_EPOCH(e_) tlp = (ra.stamps && group == 0 && (e_) == e_probe) ? ra.stamps + ((member * 2 + role) * 4 + wave) * 128 : nullptr
 #else
 #define DTL_EPOCH(e_) do { } while (0)
 #endif
@@ -435,9 +456,15 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 
     if (role == 0) {
         // =====================================================================================================
-        // role A
+        // role A: own (partial gradients -> RK update -> next stage state), P1, P2
         // =====================================================================================================
-        for (int i = tid; i < 4 * DU_KBD * 64; i += 256) L4[(DA_K1 >> 2) + i] = ws4[dp.oK1 + (long)member * 4 * DU_KBD * 64 + i];
+        // P1's A operand: this wave's 16 rows of K0, 40 VGPRs (the AccVGPR half of the 256-register budget is the K1 slice)
+        f32x4 K0r[DU_KBD];
+        {
+            const long b1 = dp.oK1 + (long)(member * 4 + wave) * DU_KBD * 64 + lane;
+#pragma unroll
+            for (int kb = 0; kb < DU_KBD; ++kb) { const float4 a = ws4[b1 + kb * 64]; K0r[kb] = (f32x4){a.x, a.y, a.z, a.w}; }
+        }
         for (int i = tid; i < 16 * DU_DP; i += 256) lds[DA_A + i] = ws[dp.oA + i];
         if (tid < DU_DP) lds[DA_CW + tid] = ws[dp.oCW + tid];
         if (tid < 192) lds[DA_VEC + tid] = ws[dp.oVec + (tid >> 6) * 64 * DU_G + member * 64 + (tid & 63)];
@@ -451,27 +478,34 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             lds[DA_T + s * DS_STRIDE + DS_XS + c] = (c == d) ? (float)ra.t0 : v;
         }
         __syncthreads();
-        // (no s_barrier below this line in role A: every wave runs on its own)
         const float cAlphQ = (float)pb.alphQ, cAlphW = (float)pb.alphW;
         const bool cWantW = want_W(pb);
         const float c16 = (float)(1.0 / 6.0), c26 = (float)(2.0 / 6.0);
+        int rA = dp.r; DU_PIN(rA);
         // Owner units are SAMPLES: own sample s = 2 t + j (sample 2 member + j of tile t) belongs to wave s & 3; lane l < 40 of that
         // wave keeps the piece dims 4 l .. 4 l + 3 = (dim tile mt = l / 4, slot sl = l % 4) of the sample.
         const bool pact = lane < 40;
-        const int pmt = lane >> 2, psl = lane & 3, pi = 4 * lane;
+        const int pmt = lane >> 2, psl = lane & 3, pi = pact ? 4 * lane : 0;
         const int pd_lane = d >> 2, pd_e = d & 3;                     // where g[d] = dPhi/dt sits
 
-        // g of own sample s at evaluation parity parG: fixed-order sum of the 8 members' partials + A^T (A s) + c
-        auto gather_g = [&](int s, int parG) -> f32x4 {
+        // Requests for the 8 members' partial gradients of own sample s (evaluation parity parG): this lane's 16 bytes of each.
+        auto g_request = [&](int s, int parG, u32x4 (&pv)[DU_G]) {
             const int t = s >> 1, j = s & 1;
-            const int lp = (psl * 16 + 2 * member + j) * 16;
-            const int sb = xG + ((parG * NT + t) * DU_G * DU_KBD + (pact ? pmt : 0)) * 1024;
-            u32x4 pv[DU_G];
+            // (per-lane parts of an address go into the VECTOR offset: a per-lane scalar offset makes hipcc serialise the access
+            // in a waterfall loop over its distinct values -- 80 iterations for these 8 loads, 11 k cycles in the first version)
+            const int lp = (psl * 16 + 2 * member + j) * 16 + (pact ? pmt : 0) * 1024;
+            const int sb = xG + ((parG * NT + t) * DU_G * DU_KBD) * 1024;
+#pragma unroll
+            for (int mem = 0; mem < DU_G; ++mem) pv[mem] = du_ld(g, lp, sb + mem * DU_KBD * 1024);
+        };
+        // g of own sample s: fixed-order sum of the partials + A^T (A s) + c.  have: pv already holds the answer of an earlier request
+        // (issued in front of the previous tile's P2, one L2 round trip off the critical path); it is used if it shows no sentinel.
+        auto gather_g = [&](int s, int parG, bool have, u32x4 (&pv)[DU_G]) -> f32x4 {
             int spins = 0;
             while (true) {
+                if (!have) g_request(s, parG, pv);
+                have = false;
                 bool bad = false;
-#pragma unroll
-                for (int mem = 0; mem < DU_G; ++mem) pv[mem] = du_ld(g, lp, sb + mem * DU_KBD * 1024);
 #pragma unroll
                 for (int mem = 0; mem < DU_G; ++mem) bad |= du_bad(pv[mem]);
                 if (!__any(bad && pact)) break;
@@ -480,27 +514,32 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             f32x4 gs = du_f(pv[0]);
 #pragma unroll
             for (int mem = 1; mem < DU_G; ++mem) gs += du_f(pv[mem]);
-            const float4 z = L4[(DA_T + s * DS_STRIDE + DS_AZC + (pact ? pi : 0)) >> 2];
+            const float4 z = L4[(DA_T + s * DS_STRIDE + DS_AZC + pi) >> 2];
             gs += (f32x4){z.x, z.y, z.z, z.w};
             return gs;
         };
 
-        // the owner's step: gradient of evaluation e-1 -> RK update -> stage state of evaluation e published -> costs integrated
-        auto owner_step = [&](int s, int e, float hs, int pst, float t_pub) {
+        // the owner's step, state part: gradient of evaluation e-1 -> RK update -> stage state of evaluation e published.
+        // Leaves this lane's share of sum p^2 (q0) and its candidate for dPhi/dt (gdv) for the cost part.
+        auto own_state = [&](int s, int e, float hs, int pst, float t_pub, bool have, u32x4 (&pv)[DU_G], float& q0, float& gdv) {
             const int t = s >> 1, j = s & 1;
             const int parG = (e - 1) & 1, parS = e & 1;
             const bool rk_last = (pst == nstage - 1);
             const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
             const float rk_wx = (pst < 2) ? 0.5f : 1.f;
-            DTL(40 * t + 0);
-            const f32x4 gs = gather_g(s, parG);
-            DTL(40 * t + 1);
             const int sbase = DA_T + s * DS_STRIDE;
-            f32x4 xs = {0.f, 0.f, 0.f, 0.f};
+            DTL(40 * t + 0);
+            const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2];      // (in flight while the partials are polled)
+            const f32x4 gs = gather_g(s, parG, have, pv);
+            DTL(40 * t + 1);
+            q0 = 0.f;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) if (pact && pi + e4 < d) q0 += gs[e4] * gs[e4];
+            gdv = pd_e == 0 ? gs[0] : (pd_e == 1 ? gs[1] : (pd_e == 2 ? gs[2] : gs[3]));
             if (pact) {
-                const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2];
                 const float z0[4] = {z04.x, z04.y, z04.z, z04.w};
                 float zA[4] = {zA4.x, zA4.y, zA4.z, zA4.w}, zn[4];
+                f32x4 xs;
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int i = pi + e4;
@@ -512,9 +551,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     xs[e4] = (i < d) ? x_ : (i == d ? t_pub : 0.f);
                     if (i >= d) { zn[e4] = 0.f; zA[e4] = 0.f; }
                 }
-                const int lp = (psl * 16 + 2 * member + j) * 16;
-                du_st(g, lp, xS + ((parS * NT + t) * DU_KBD + pmt) * 1024, xs);
-                du_st_sent(g, lp, xS + (((parS ^ 1) * NT + t) * DU_KBD + pmt) * 1024);
+                const int lp = (psl * 16 + 2 * member + j) * 16 + pmt * 1024;
+                du_st(g, lp, xS + ((parS * NT + t) * DU_KBD) * 1024, xs);
+                du_st_sent(g, lp, xS + (((parS ^ 1) * NT + t) * DU_KBD) * 1024);
                 if (rk_last) L4[(sbase + DS_Z0 + pi) >> 2] = make_float4(zn[0], zn[1], zn[2], zn[3]);
                 else L4[(sbase + DS_ZA + pi) >> 2] = make_float4(zA[0], zA[1], zA[2], zA[3]);
                 L4[(sbase + DS_XS + pi) >> 2] = make_float4(xs[0], xs[1], xs[2], xs[3]);
@@ -526,12 +565,16 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 }
             }
             DTL(40 * t + 2);
-            // ---- cost side of evaluation e-1 (after the state has been sent): sum p^2, dPhi/dt, the x-only terms from role B
-            float q0 = 0.f;
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) if (pact && pi + e4 < d) q0 += gs[e4] * gs[e4];
+        };
+        // ... cost part (off the critical path: it runs behind P1, while the u0 exchange travels): sum p^2, dPhi/dt, the x-only terms
+        // from role B -> the four cost integrals of evaluation e-1
+        auto own_costs = [&](int s, int e, float hs, int pst, float q0, float gdv, bool have, unsigned qa, unsigned qb) {
+            const int t = s >> 1, j = s & 1;
+            const int parG = (e - 1) & 1;
+            const bool rk_last = (pst == nstage - 1);
+            const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
+            const int sbase = DA_T + s * DS_STRIDE;
             const float sp2 = sum64(q0);
-            const float gdv = pd_e == 0 ? gs[0] : (pd_e == 1 ? gs[1] : (pd_e == 2 ? gs[2] : gs[3]));
             const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gdv), pd_lane));
             // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
             float q_ = 0.f, w_ = 0.f;
@@ -539,9 +582,10 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const int ob = xQ + (((parG * NT + t) * DU_G + member) * 4 + 2 * j) * 4;
                 int spins = 0;
                 while (true) {
-                    const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, ob, 16);
-                    q_ = __uint_as_float(v2[0]); w_ = __uint_as_float(v2[1]);
-                    if (!__any(v2[0] == DU_SENT || v2[1] == DU_SENT)) break;
+                    if (!have) { const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, ob, 16); qa = v2[0]; qb = v2[1]; }
+                    have = false;
+                    q_ = __uint_as_float(qa); w_ = __uint_as_float(qb);
+                    if (!__any(qa == DU_SENT || qb == DU_SENT)) break;
                     if (du_spin(g, spins, DUK_Q)) break;
                 }
             }
@@ -562,16 +606,21 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             DTL(40 * t + 3);
         };
 
-        // z = A s and A^T z + c of own sample s at its CURRENT stage state (needed when the gradient of this evaluation arrives)
+        // z = A s and A^T z + c of own sample s at its CURRENT stage state (needed when the gradient of this evaluation arrives).
+        // LDS reads in batches that are in flight together (a dependent read costs ~130 cycles when waited for alone).
         auto azc_step = [&](int s, bool fin) {
             const int sbase = DA_T + s * DS_STRIDE;
             {
                 const int q = lane >> 2, part = lane & 3;            // row of A, quarter of the dims (10 float4 each)
+                const int ia = ((DA_A + q * DU_DP) >> 2) + part * 10, ix = ((sbase + DS_XS) >> 2) + part * 10;
                 float acc = 0.f;
-#pragma unroll 5
-                for (int i4 = 0; i4 < 10; ++i4) {
-                    const float4 a = L4[((DA_A + q * DU_DP) >> 2) + part * 10 + i4], x4 = L4[((sbase + DS_XS) >> 2) + part * 10 + i4];
-                    acc += (a.x * x4.x + a.y * x4.y) + (a.z * x4.z + a.w * x4.w);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float4 a[5], x4[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) { a[i] = L4[ia + 5 * h + i]; x4[i] = L4[ix + 5 * h + i]; }
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) acc += (a[i].x * x4[i].x + a[i].y * x4[i].y) + (a[i].z * x4[i].z + a[i].w * x4[i].w);
                 }
                 acc = sum4(acc);
                 if (part == 0) lds[sbase + DS_ZQ + q] = acc;
@@ -580,10 +629,17 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             if (pact) {
                 const float4 c4 = L4[(DA_CW + pi) >> 2];
                 float o[4] = {c4.x, c4.y, c4.z, c4.w};
-                for (int q = 0; q < dp.r; ++q) {
-                    const float z = lds[sbase + DS_ZQ + q];
-                    const float4 a = L4[(DA_A + q * DU_DP + pi) >> 2];
-                    o[0] += a.x * z; o[1] += a.y * z; o[2] += a.z * z; o[3] += a.w * z;
+#pragma unroll
+                for (int qb = 0; qb < 16; qb += 4) {                 // rows of A beyond r are zero
+                    if (qb < rA) {
+                        const float4 z4 = L4[(sbase + DS_ZQ + qb) >> 2];
+                        float4 a[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[i] = L4[(DA_A + (qb + i) * DU_DP + pi) >> 2];
+                        const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { o[0] += a[i].x * z[i]; o[1] += a[i].y * z[i]; o[2] += a[i].z * z[i]; o[3] += a[i].w * z[i]; }
+                    }
                 }
                 L4[(sbase + DS_AZC + pi) >> 2] = make_float4(o[0], o[1], o[2], o[3]);
                 if (fin) { const float4 x4 = L4[(sbase + DS_XS + pi) >> 2]; lin = (c4.x * x4.x + c4.y * x4.y) + (c4.z * x4.z + c4.w * x4.w); }
@@ -592,7 +648,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const float ls = sum64(lin);
                 if (lane == 0) {
                     float qd = 0.f;
-                    for (int q = 0; q < dp.r; ++q) { const float z = lds[sbase + DS_ZQ + q]; qd += 0.5f * z * z; }
+                    for (int q = 0; q < rA; ++q) { const float z = lds[sbase + DS_ZQ + q]; qd += 0.5f * z * z; }
                     lds[sbase + DS_PHX] = ls;
                     lds[sbase + DS_PHX + 1] = qd;
                 }
@@ -604,7 +660,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             const int t = s >> 1, j = s & 1, sbase = DA_T + s * DS_STRIDE;
             if (pact) {
                 const float4 x4 = L4[(sbase + DS_XS + pi) >> 2];
-                du_st(g, (psl * 16 + 2 * member + j) * 16, xS + ((1 * NT + t) * DU_KBD + pmt) * 1024, (f32x4){x4.x, x4.y, x4.z, x4.w});
+                du_st(g, (psl * 16 + 2 * member + j) * 16 + pmt * 1024, xS + ((1 * NT + t) * DU_KBD) * 1024, (f32x4){x4.x, x4.y, x4.z, x4.w});
             }
             if (REC && ra.sAll && own_row(t, j) < ra.n)
                 for (int i = lane; i <= d; i += 64) ra.sAll[(rr.row0 + own_row(t, j)) * (d + 1) + i] = lds[sbase + DS_XS + i];
@@ -613,6 +669,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         double tk = ra.t0;
         int e = 0;
         float p_hs = 0.f; int p_st = 0;
+        u32x4 pf[DU_G];                                            // prefetched partial gradients of own sample pf_s (-1: none)
+        unsigned pf_qa = 0, pf_qb = 0;
+        int pf_s = -1;
         for (int k = 0; k <= ra.nt; ++k) {
             const bool fin = (k == ra.nt);
             const double t1k = tk + ra.h;
@@ -624,55 +683,92 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 // time of this evaluation: stepRK4's t0, t0 + h/2, t0 + h/2, t0 + h in double (src/OCflow.py:157-184); the terminal
                 // evaluation runs at tspan[1] (src/OCflow.py:62)
                 const double te = fin ? ra.t1 : ((nstage == 1 || st == 0) ? tk : (st == 3 ? tk + hsd : tk + hsd / 2));
+                // tile after tile: while this workgroup multiplies tile t, role B works on the tile before it
                 for (int t = 0; t < NT; ++t) {
-                    if (e > 1) {
-                        if (((2 * t) & 3) == wave) owner_step(2 * t, e, p_hs, p_st, (float)te);
-                        if (((2 * t + 1) & 3) == wave) owner_step(2 * t + 1, e, p_hs, p_st, (float)te);
-                    }
+                    const int s0 = 2 * t, s1 = 2 * t + 1;
+                    const int sown = ((s0 & 3) == wave) ? s0 : (((s1 & 3) == wave) ? s1 : -1);      // this wave's own sample of the tile, if any
+                    float cq0 = 0.f, cgd = 0.f;
+                    const bool pf_have = pf_s == sown && sown >= 0;                 // the partials were requested in front of the previous P2
+                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, (float)te, pf_have, pf, cq0, cgd);
+                    const unsigned qa_ = pf_qa, qb_ = pf_qb;
+                    pf_s = -1;
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
-                    const f32x4 acc = du_gemm<DU_KBD, true>(g, W, (DA_K1 >> 2) + wave * DU_KBD * 64 + lane, vb, xS + ((par * NT + t) * DU_KBD) * 1024, DUK_S, [&]() { DTL(40 * t + 5); });
-                    DTL(40 * t + 6);
-                    const float4 b0s = L4[(DA_VEC >> 2) + 4 * wave + slot];    // bias of this lane's 4 features 16 wave + 4 slot + e
-                    const float b0v[4] = {b0s.x, b0s.y, b0s.z, b0s.w};
-                    f32x4 sg, th;
+                    du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
+                    __syncthreads();
+                    DTL(40 * t + 5);
+                    {
+                        const f32x4 acc = du_gemm_lds<DU_KBD, false>(K0r, (DA_SF >> 2) + lane);
+                        DTL(40 * t + 6);
+                        const float4 b0s = L4[(DA_VEC >> 2) + 4 * wave + slot];    // bias of this lane's 4 features 16 wave + 4 slot + e
+                        const float b0v[4] = {b0s.x, b0s.y, b0s.z, b0s.w};
+                        f32x4 sg, th;
 #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) { float s_, t_; act_pair(acc[e4] + b0v[e4], s_, t_); sg[e4] = s_; th[e4] = t_; }
-                    const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, fr = (((par ^ 1) * NT + t) * DU_KBM + 4 * member + wave) * 1024;
-                    du_st(g, vb, xU + fo, sg);
-                    du_st(g, vb, xT + fo, th);
-                    du_st_sent(g, vb, xU + fr);
-                    du_st_sent(g, vb, xT + fr);
-                    du_st_sent(g, vb, xV + fr);                     // (V one phase early: header, H1)
+                        for (int e4 = 0; e4 < 4; ++e4) { float s_, t_; act_pair(acc[e4] + b0v[e4], s_, t_); sg[e4] = s_; th[e4] = t_; }
+                        const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, fr = (((par ^ 1) * NT + t) * DU_KBM + 4 * member + wave) * 1024;
+                        du_st(g, vb, xU + fo, sg);
+                        du_st(g, vb, xT + fo, th);
+                        du_st_sent(g, vb, xU + fr);
+                        du_st_sent(g, vb, xT + fr);
+                        du_st_sent(g, vb, xV + fr);                 // (V one phase early: header, H1)
+                    }
                     DTL(40 * t + 7);
-                }
-                DTL(8);
-                for (int s = wave; s < 2 * NT; s += 4) azc_step(s, fin);
-                DTL(9);
-                for (int t = 0; t < NT; ++t) {
+                    // (in the shadow of the u0 exchange) the cost integrals of the previous evaluation; z = A s, A^T z + c of the own sample
+                    if (sown >= 0) {
+                        if (e > 1) own_costs(sown, e, p_hs, p_st, cq0, cgd, pf_have, qa_, qb_);
+                        azc_step(sown, fin);
+                    }
+                    DTL(40 * t + 8);
+                    // With several tiles per group the partial gradients of the NEXT tile's own sample have usually arrived by now (role B
+                    // worked on that tile while this workgroup multiplied this one): request them (and the cost scalars) here, so that their
+                    // L2 round trip runs under P2 instead of in front of the next owner's step.
+                    if (DU_PREFETCH_G && NT > 1 && !fin) {
+                        const int tn = (t + 1 < NT) ? t + 1 : 0, en = (t + 1 < NT) ? e : e + 1;
+                        const int n0 = 2 * tn, n1 = 2 * tn + 1;
+                        const int sn = ((n0 & 3) == wave) ? n0 : (((n1 & 3) == wave) ? n1 : -1);
+                        if (sn >= 0 && en > 1) {
+                            pf_s = sn;
+                            g_request(sn, (en - 1) & 1, pf);
+                            const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((en - 1) & 1) * NT + tn) * DU_G + member) * 4 + 2 * (sn & 1)) * 4, 16);
+                            pf_qa = v2[0]; pf_qb = v2[1];
+                        }
+                    }
                     // ================= P2: q = K1[H_c,:] u0 + b1 ; v = tanh(q) . w =================
+                    du_gather<DU_KBM>(g, wave, lane, xU + ((par * NT + t) * DU_KBM) * 1024, DA_UF >> 2, DUK_U);
+                    __syncthreads();
                     DTL(40 * t + 10);
-                    const f32x4 acc = du_gemm<DU_KBM, false>(g, W, 0, vb, xU + ((par * NT + t) * DU_KBM) * 1024, DUK_U, [&]() { DTL(40 * t + 11); });
-                    DTL(40 * t + 12);
-                    const float4 b1s = L4[((DA_VEC + 64) >> 2) + 4 * wave + slot], wvs = L4[((DA_VEC + 128) >> 2) + 4 * wave + slot];
-                    const float b1v[4] = {b1s.x, b1s.y, b1s.z, b1s.w}, wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
-                    f32x4 v;
+                    {
+                        const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DA_UF >> 2) + lane);
+                        DTL(40 * t + 11);
+                        const float4 b1s = L4[((DA_VEC + 64) >> 2) + 4 * wave + slot], wvs = L4[((DA_VEC + 128) >> 2) + 4 * wave + slot];
+                        const float b1v[4] = {b1s.x, b1s.y, b1s.z, b1s.w}, wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
+                        f32x4 v;
+#ifdef NOCF_STAMPS
+                        asm volatile("" : "+v"(v) : "v"(b1s.x), "v"(wvs.x));
+                        DTL(40 * t + 16);
+#endif
 #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) v[e4] = tanh_fast(acc[e4] + b1v[e4]) * wv[e4];
-                    du_st(g, vb, xV + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, v);
-                    DTL(40 * t + 13);
-                    if (fin) {
-                        // w . u_1 = w . (u_0 + hN sigma(q)) over this wave's 16 features (src/Phi.py:91-96): own u_0 fragment back from the exchange
-                        const f32x4 u0 = du_f(du_ld(g, vb, xU + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024));
-                        float pr = 0.f;
+                        for (int e4 = 0; e4 < 4; ++e4) v[e4] = tanh_fast(acc[e4] + b1v[e4]) * wv[e4];
+#ifdef NOCF_STAMPS
+                        asm volatile("" : "+v"(v));
+                        DTL(40 * t + 17);
+#endif
+                        du_st(g, vb, xV + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, v);
+                        DTL(40 * t + 12);
+                        if (fin) {
+                            // w . u_1 = w . (u_0 + hN sigma(q)) over this wave's 16 features (src/Phi.py:91-96): own u_0 fragment from the staged tile
+                            const float4 u4 = L4[(DA_UF >> 2) + (4 * member + wave) * 64 + lane];
+                            const float u0[4] = {u4.x, u4.y, u4.z, u4.w};
+                            float pr = 0.f;
 #pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) pr += wv[e4] * (u0[e4] + hN * sigma_act(acc[e4] + b1v[e4]));
-                        pr += __shfl_xor(pr, 16); pr += __shfl_xor(pr, 32);
-                        if (lane < 16) {
-                            const unsigned pu = __float_as_uint(pr);
-                            const int off = xP + (((t * DU_G + member) * 4 + wave) * 16 + lane) * 4;
-                            if (g.fast) __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 0);
-                            else __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 16);
+                            for (int e4 = 0; e4 < 4; ++e4) pr += wv[e4] * (u0[e4] + hN * sigma_act(acc[e4] + b1v[e4]));
+                            pr += __shfl_xor(pr, 16); pr += __shfl_xor(pr, 32);
+                            if (lane < 16) {
+                                const unsigned pu = __float_as_uint(pr);
+                                const int off = xP + (((t * DU_G + member) * 4 + wave) * 16 + lane) * 4;
+                                if (g.fast) __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 0);
+                                else __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 16);
+                            }
                         }
                     }
                 }
@@ -684,7 +780,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // ---- terminal costs of the own samples (src/OCflow.py:58-76): gradient and Phi of the terminal evaluation
         for (int s = wave; s < 2 * NT; s += 4) {
             const int t = s >> 1, j = s & 1, sbase = DA_T + s * DS_STRIDE;
-            const f32x4 gs = gather_g(s, e & 1);
+            const f32x4 gs = gather_g(s, e & 1, false, pf);
             float r2 = 0.f, hg = 0.f;
             if (pact) {
                 const float4 z = L4[(sbase + DS_Z0 + pi) >> 2];
@@ -724,78 +820,65 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         }
     } else {
         // =====================================================================================================
-        // role B
+        // role B: x-only cost terms, P3, P4
         // =====================================================================================================
         for (int i = tid; i < DU_KBD * 4 * 64; i += 256) L4[(DB_K4 >> 2) + i] = ws4[dp.oK4 + (long)member * DU_KBD * 4 * 64 + i];
         if (tid < 64) lds[DB_VEC + tid] = ws[dp.oVec + 2 * 64 * DU_G + member * 64 + tid];
         __syncthreads();
-        const float4 wvs = L4[(DB_VEC >> 2) + 4 * wave + slot];
-        const float wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
         const DXPar xp = du_x_params(pb, PD);
-        const int NP = xp.N * xp.P, IT = 2 * NP;                 // cost-pass items per sample / per tile
-        const int lXB = DB_XB(NT), lXP = DB_XP(NT);
         const int E = ra.nt * nstage + 1;
         for (int e = 1; e <= E; ++e) {
             const bool fin = (e == E);
             const int par = e & 1;
             DTL_EPOCH(e);
-            DTL(20);
-            if (!fin) {
-                // ================= x-only cost terms of the own samples at the state of evaluation e =================
-                for (int pb0 = 0; pb0 < NT * 80; pb0 += 256) {      // (uniform trip count: the polls inside stay wave-uniform)
-                    const int p = pb0 + tid;
-                    const bool valid = p < NT * 80;
-                    const int pc = valid ? p : 0;
-                    const int t = pc / 80, q = pc - t * 80, j = q >= 40 ? 1 : 0, r_ = q - 40 * j, mt = r_ >> 2, sl = r_ & 3;
-                    const int off = xS + ((par * NT + t) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16;
-                    u32x4 v;
-                    int spins = 0;
-                    while (true) {
-                        v = du_ld(g, off, 0);
-                        if (!__any(du_bad(v))) break;
-                        if (du_spin(g, spins, DUK_S)) break;
+            for (int t = 0; t < NT; ++t) {
+                DTL(40 * t + 20);
+                if (!fin) {
+                    // ================= x-only cost terms of the own samples of tile t at the state of evaluation e =================
+                    if (wave < 2) {                                     // 80 pieces of 16 B: dims 4 l .. 4 l + 3 of own sample j
+                        const int p = tid < 80 ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, mt = r_ >> 2, sl = r_ & 3;
+                        const int off = xS + ((par * NT + t) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16;
+                        u32x4 v;
+                        int spins = 0;
+                        while (true) {
+                            v = du_ld(g, off, 0);
+                            if (!__any(du_bad(v))) break;
+                            if (du_spin(g, spins, DUK_S)) break;
+                        }
+                        const f32x4 f = du_f(v);
+                        if (tid < 80) L4[(DB_XB + j * DU_DP + 4 * r_) >> 2] = make_float4(f[0], f[1], f[2], f[3]);
                     }
-                    const f32x4 f = du_f(v);
-                    if (valid) L4[(lXB + (t * 2 + j) * DU_DP + 16 * mt + 4 * sl) >> 2] = make_float4(f[0], f[1], f[2], f[3]);
-                }
-                __syncthreads();
-                DTL(21);
-                for (int it = tid; it < NT * IT; it += 256) {
-                    int s = 0, rem = it;
-                    while (rem >= NP) { rem -= NP; ++s; }             // s = 2 t + j
-                    float q_ = 0.f, w_ = 0.f;
-                    du_x_item<PD>(pb, xp, lds + lXB + s * DU_DP, rem >> xp.lgP, rem & (xp.P - 1), q_, w_);
-                    lds[lXP + 2 * it] = q_; lds[lXP + 2 * it + 1] = w_;
-                }
-                __syncthreads();
-                DTL(22);
-                for (int s = wave; s < 2 * NT; s += 4) {
-                    float q_ = 0.f, w_ = 0.f;
-                    for (int a = lane; a < NP; a += 64) { q_ += lds[lXP + 2 * (s * NP + a)]; w_ += lds[lXP + 2 * (s * NP + a) + 1]; }
-                    q_ = sum64(q_); w_ = sum64(w_);
-                    if (lane == 0) {
-                        const int t = s >> 1, j = s & 1;
-                        const int off = xQ + (((par * NT + t) * DU_G + member) * 4 + 2 * j) * 4;
+                    __syncthreads();
+                    DTL(40 * t + 21);
+                    {
+                        float q_ = 0.f, w_ = 0.f;
+                        du_x_wave<PD>(pb, xp, DB_XB + (wave & 1) * DU_DP, lane, wave >> 1, q_, w_);
+                        q_ = sum64(q_); w_ = sum64(w_);
+                        if (lane == 0) { lds[DB_XP + 2 * wave] = q_; lds[DB_XP + 2 * wave + 1] = w_; }
+                    }
+                    __syncthreads();
+                    DTL(40 * t + 22);
+                    if (wave == 0 && lane < 2) {                        // sample j = lane: the two halves in a fixed order
+                        const float q_ = lds[DB_XP + 2 * lane] + lds[DB_XP + 2 * (lane + 2)], w_ = lds[DB_XP + 2 * lane + 1] + lds[DB_XP + 2 * (lane + 2) + 1];
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 pay = {__float_as_uint(q_), __float_as_uint(w_)};
+                        const int off = xQ + (((par * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 16);      // (the slot is reset in P3: see there)
+                        else __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 16);      // (the slot is reset below, behind the V gather)
                     }
+                    DTL(40 * t + 23);
                 }
-            }
-            for (int t = 0; t < NT; ++t) {
                 // ================= P3: a = w + hN K1[:,H_c]^T v ; y = tanh(o) . a =================
                 const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
                 DTL(40 * t + 24);
-                u32x4 thv = du_ld(g, vb, xT + fo);
-                const int gR = xG + ((((par ^ 1) * NT + t) * DU_G + member) * DU_KBD) * 1024;
-                const f32x4 acc = du_gemm<DU_KBM, false>(g, W, 0, vb, xV + ((par * NT + t) * DU_KBM) * 1024, DUK_V, [&]() {
-                    DTL(40 * t + 25);
-                    // the partial-gradient slots of the previous evaluation: every owner has read them (it published S(e), and a V(e)
-                    // fragment exists); P3's closing vmcnt(0) then lies between this reset and the payload stored below (header, H1)
+                du_gather<DU_KBM>(g, wave, lane, xV + ((par * NT + t) * DU_KBM) * 1024, DB_VF >> 2, DUK_V);
+                {
+                    // V(e) is complete, so every owner has read the partial gradients and the cost scalars of the previous evaluation
+                    // (it published S(e) after them): reset those slots now.  The tanh(o) load below is younger than these stores, and
+                    // vmcnt retires in order: its wait lies between the resets and the payloads stored at the end of P4 (header, H1).
+                    const int gR = xG + ((((par ^ 1) * NT + t) * DU_G + member) * DU_KBD) * 1024;
 #pragma unroll
                     for (int mi = 0; mi < 3; ++mi) { const int mt = wave + 4 * mi; if (mt < DU_KBD) du_st_sent(g, vb, gR + mt * 1024); }
-                    // ... and the cost scalars of the previous evaluation: the owner reads them before its P1 of this evaluation
                     if (wave == 0 && lane < 2) {
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 sen = {DU_SENT, DU_SENT};
@@ -803,7 +886,11 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 16);
                     }
-                });
+                }
+                u32x4 thv = du_ld(g, vb, xT + fo);
+                __syncthreads();
+                DTL(40 * t + 25);
+                const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DB_VF >> 2) + lane);
                 DTL(40 * t + 26);
                 {
                     int spins = 0;
@@ -812,38 +899,47 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         thv = du_ld(g, vb, xT + fo);
                     }
                 }
-                const f32x4 th = du_f(thv);
-                float4 y;
-                y.x = th[0] * (wv[0] + hN * acc[0]); y.y = th[1] * (wv[1] + hN * acc[1]);
-                y.z = th[2] * (wv[2] + hN * acc[2]); y.w = th[3] * (wv[3] + hN * acc[3]);
-                L4[(DB_YF >> 2) + (t * 4 + wave) * 64 + lane] = y;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the resets above have landed: see there)
+                {
+                    const f32x4 th = du_f(thv);
+                    const float4 wvs = L4[(DB_VEC >> 2) + 4 * wave + slot];
+                    float4 y;
+                    y.x = th[0] * (wvs.x + hN * acc[0]); y.y = th[1] * (wvs.y + hN * acc[1]);
+                    y.z = th[2] * (wvs.z + hN * acc[2]); y.w = th[3] * (wvs.w + hN * acc[3]);
+                    L4[(DB_YF >> 2) + wave * 64 + lane] = y;
+                }
                 DTL(40 * t + 27);
                 __syncthreads();
                 DTL(40 * t + 28);
                 // ================= P4: partial g = K0[H_c,:]^T y for the dim tiles wave, wave+4, wave+8 =================
                 const int gP = xG + (((par * NT + t) * DU_G + member) * DU_KBD) * 1024;
+                {
+                    float4 bf[4], wf[2][4];
 #pragma unroll
-                for (int mi = 0; mi < 3; ++mi) {
-                    const int mt = wave + 4 * mi;
-                    if (mt < DU_KBD) {
-                        f32x4 a0, a1;
-                        float4 wf[4], bf[4];
+                    for (int kb = 0; kb < 4; ++kb) { bf[kb] = L4[(DB_YF >> 2) + kb * 64 + lane]; wf[0][kb] = L4[(DB_K4 >> 2) + (wave * 4 + kb) * 64 + lane]; }
 #pragma unroll
-                        for (int kb = 0; kb < 4; ++kb) {
-                            wf[kb] = L4[(DB_K4 >> 2) + (mt * 4 + kb) * 64 + lane];
-                            bf[kb] = L4[(DB_YF >> 2) + (t * 4 + kb) * 64 + lane];
+                    for (int mi = 0; mi < 3; ++mi) {
+                        const int mt = wave + 4 * mi;
+                        if (mt < DU_KBD) {
+                            if (mi < 2 && mt + 4 < DU_KBD) {
+#pragma unroll
+                                for (int kb = 0; kb < 4; ++kb) wf[(mi + 1) & 1][kb] = L4[(DB_K4 >> 2) + ((mt + 4) * 4 + kb) * 64 + lane];
+                            }
+                            const float4 (&w4)[4] = wf[mi & 1];
+                            f32x4 a0, a1;
+                            mfma_v0(a0, w4[0].x, bf[0].x); mfma_v0(a1, w4[0].y, bf[0].y);
+                            mfma_v(a0, w4[0].z, bf[0].z); mfma_v(a1, w4[0].w, bf[0].w);
+#pragma unroll
+                            for (int kb = 1; kb < 4; ++kb) {
+                                mfma_v(a0, w4[kb].x, bf[kb].x); mfma_v(a1, w4[kb].y, bf[kb].y);
+                                mfma_v(a0, w4[kb].z, bf[kb].z); mfma_v(a1, w4[kb].w, bf[kb].w);
+                            }
+                            DU_FENCE2(a0, a1);
+                            du_st(g, vb, gP + mt * 1024, a0 + a1);
                         }
-                        mfma_v0(a0, wf[0].x, bf[0].x); mfma_v0(a1, wf[0].y, bf[0].y);
-                        mfma_v(a0, wf[0].z, bf[0].z); mfma_v(a1, wf[0].w, bf[0].w);
-#pragma unroll
-                        for (int kb = 1; kb < 4; ++kb) {
-                            mfma_v(a0, wf[kb].x, bf[kb].x); mfma_v(a1, wf[kb].y, bf[kb].y);
-                            mfma_v(a0, wf[kb].z, bf[kb].z); mfma_v(a1, wf[kb].w, bf[kb].w);
-                        }
-                        DU_FENCE2(a0, a1);
-                        du_st(g, vb, gP + mt * 1024, a0 + a1);
                     }
                 }
+                if (dp.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 DTL(40 * t + 29);
             }
         }
@@ -870,7 +966,7 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
     dp.NT = (int)((ntiles + dp.ngroups - 1) / dp.ngroups);
     if (dp.NT > DU_NTMAX) return NOCF_E_SHAPE;
     dp.hN = 1.0f;
-    const int ldsA = DA_T + 2 * dp.NT * DS_STRIDE, ldsB = DB_XP(dp.NT) + dp.NT * 512;
+    const int ldsA = DA_T + 2 * dp.NT * DS_STRIDE, ldsB = DB_END;
     dp.ldsFloats = std::max(ldsA, ldsB);
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
     long o = 0;                                                                    // floats
@@ -938,6 +1034,7 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
         dp.cb = phi->cb;
         dp.fast = du_env_int("NOCF_DUO_FAST", 1);
         dp.mapmode = du_env_int("NOCF_DUO_MAP", 0);
+        dp.dbg = du_env_int("NOCF_DUO_DBG", 0);
         dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
         hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws);     // (every chunk: the plan record changes with the chunk's rows)
         if (r0 == 0) { e = hipMemsetAsync(ws + dp.oErr, 0, 64 * 4, st); if (e) return (int)e; }
