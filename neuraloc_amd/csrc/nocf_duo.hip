@@ -73,13 +73,15 @@ enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P =
 #define DS_CZ 656                                  // [8]   cost integrals L, HJt, Q, W: value, RK accumulator
 #define DS_PHX 664                                 // [2]   c.s and 1/2 |A s|^2 (final time)
 #define DS_STRIDE 672
-// Role B: P4's A-operand image, w slice, the staged v tile, the y fragments, the own states of the current tile, cost partials
+// Role B: P4's A-operand image, w slice, the staged v tile, the y fragments (also: the positions of the cost pass), cost partials
 #define DB_K4 0                                    // [10 mt][4 kb][64][4]
 #define DB_VEC (DB_K4 + DU_KBD * 4 * 256)          // w, 64
 #define DB_VF (DB_VEC + 64)                        // staged v tile: [32 kb][64][4]
 #define DB_YF (DB_VF + DU_KBM * 256)               // [4 waves][64][4]
-#define DB_XB (DB_YF + 1024)                       // [2][160]
-#define DB_XP (DB_XB + 2 * DU_DP)                  // [4 waves][2]
+#define DB_XA DB_VF                                // [2 samples][2 N <= 128 entries][4]: the own samples' positions of the cost pass.  Aliases the head of the
+                                                   // staged v tile: written at a tile's entry (every wave is past the previous tile's y barrier, i.e. past its
+                                                   // P3 reads of VF), read before the barrier in front of this tile's V gather
+#define DB_XP (DB_YF + 1024)                       // [4 waves][2]
 #define DB_END (DB_XP + 16)
 
 struct DuoPlan {
@@ -89,7 +91,7 @@ struct DuoPlan {
     int dbg, pad_;                 // (spare)
     long oW2, oW3, oK1, oK4;        // float4 offsets of the images in the workspace
     long oA, oVec, oCW;             // float offsets: A [16][160], b0 | b1 | w [3][512], c.weight [160]
-    long oPlan, oErr, oXcc, oX, xStride;
+    long oPlan, oErr, oXcc, oCen, oX, xStride;
 };
 static_assert(sizeof(DuoPlan) % 4 == 0 && sizeof(DuoPlan) / 4 <= 256, "plan copy is done by one 256-thread block");
 
@@ -316,51 +318,47 @@ __device__ __forceinline__ DXPar du_x_params(const DevProb& pb, int PD) {
     xp.Jh = (xp.JJ + 1) >> 1;                                         // the two halves of the partner range: [1, Jh], (Jh, JJ]
     return xp;
 }
-// One wave = one own sample x one half of the partner range; lane a < N is agent a (its position stays in registers), the partners'
-// positions come from the sample's LDS row through a pointer that advances one agent per partner (consecutive lanes read consecutive
-// agents: conflict-free; no per-partner index arithmetic).  Half 0 adds the obstacle terms.  Straight-line selects, no per-pair
-// branches; every unordered pair is counted once.  Returns this lane's partial sums.
+// One wave = one own sample x one half of the partner range; lane a < N is agent a.  The sample's positions sit in LDS as
+// [2 N entries][4 floats] (entry i and i + N are the same agent, the fourth float is padding): the partner (a + j) mod N is entry
+// a + j -- no wrap, one ds_read_b128 per partner, consecutive lanes read consecutive entries.  Half 0 adds the obstacle terms.
+// Straight-line selects, no per-pair branches; every unordered pair is counted once.  Returns this lane's partial sums.
 template <int PD>
-__device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, int xoff /* LDS float index of the sample's row */, int lane, int half,
+__device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, int x4 /* LDS float4 index of the sample's entries */, int lane, int half,
                                           float& qacc, float& wacc) {
     const int N = xp.N;
+    const float4* L4 = reinterpret_cast<const float4*>(lds);
     const bool act = lane < N;
     const int a = act ? lane : 0;
-    float xa[PD];
-#pragma unroll
-    for (int k = 0; k < PD; ++k) xa[k] = lds[xoff + PD * a + k];
+    const float4 me = L4[x4 + a];
     if (half == 0 && xp.obs) {
-        const float ob = (PD == 2) ? obstacle_cross2d(pb, xa[0], xa[1]) : obstacle_swarm(pb, xa[0], xa[1], xa[PD - 1]);
+        const float ob = (PD == 2) ? obstacle_cross2d(pb, me.x, me.y) : obstacle_swarm(pb, me.x, me.y, me.z);
         qacc += act ? ob : 0.f;
     }
     if (!xp.wantW) return;
     if (N == 2) {
         if (half == 0 && lane == 0) {
-            float s2 = 0.f;
-            for (int k = 0; k < PD; ++k) { const float e = lds[xoff + k] - lds[xoff + PD + k]; s2 += e * e; }
+            const float4 o = L4[x4 + 1];
+            float s2 = (me.x - o.x) * (me.x - o.x); s2 += (me.y - o.y) * (me.y - o.y);
+            if (PD == 3) s2 += (me.z - o.z) * (me.z - o.z);
             const float dist = sqrtf(s2);
             if (dist < xp.thr_pair2) wacc += expf(-(dist * dist) / xp.den);
         }
         return;
     }
     const int jlo = half ? xp.Jh + 1 : 1, jhi = half ? xp.JJ : xp.Jh;           // partners jlo..jhi (inclusive)
-    const bool lowhalf = a < (N >> 1);                                          // the opposite agent (even N) counts from the lower half only
-    int b = a + jlo; b -= (b >= N) ? N : 0;
-    int pp = xoff + PD * b;
-    const int pend = xoff + PD * N;
+    const bool actlow = act & (a < (N >> 1));                                   // the opposite agent (even N) counts from the lower half only
     constexpr int XW = 5;                                   // partners per round (their LDS reads are in flight together)
     for (int j = jlo; j <= jhi; j += XW) {
+        float4 p[XW];
+#pragma unroll
+        for (int u = 0; u < XW; ++u) p[u] = L4[x4 + a + j + u];
         float s2[XW];
 #pragma unroll
         for (int u = 0; u < XW; ++u) {
-            float xb[PD];
-#pragma unroll
-            for (int k = 0; k < PD; ++k) xb[k] = lds[pp + k];
-            pp += PD; pp -= (pp >= pend) ? PD * N : 0;
-            float a2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < PD; ++k) { const float e = xa[k] - xb[k]; a2 += e * e; }
-            const bool valid = act & (j + u <= jhi) & ((j + u <= xp.J) | lowhalf);
+            const float e0 = me.x - p[u].x, e1 = me.y - p[u].y;
+            float a2 = e0 * e0; a2 += e1 * e1;
+            if (PD == 3) { const float e2 = me.z - p[u].z; a2 += e2 * e2; }
+            const bool valid = (j + u <= jhi) & ((j + u <= xp.J) ? act : actlow);
             s2[u] = valid ? a2 : 3.0e38f;
         }
         bool near = false;
@@ -393,12 +391,63 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     const DuoPlan& dp = *dpp;
     const int bid = blockIdx.x;
     const int jb = bid >> 3;
-    const int group = (bid & 7) + 8 * (jb >> 4);
+    const int tid = threadIdx.x;
+    // ---- who am I?  Static map: workgroups with equal blockIdx % 8 (one XCD under round-robin dispatch) form the groups.  Census map
+    // (default): the two workgroups that share a CU become role A and role B of the SAME (group, member).  Their MFMA phases then
+    // alternate on that CU's matrix pipes by construction, and all members of a group see the same interference, so nobody waits for a
+    // straggler whose CU-mate belongs to another group (static map at 2 workgroups per CU: 29 % longer evaluations than at 1 per CU).
+    // Every workgroup registers on its CU's counter (key: SE / SH / CU id of HW_REG_HW_ID); the first one per CU draws the CU's rank in
+    // its XCD slot; when all workgroups of the slot have arrived and #CUs x 2 = #workgroups (every CU holds exactly two), rank r is
+    // (group r / 8 of the slot, member r % 8), the first-arrived workgroup takes role A.  Otherwise the slot keeps the static map.
+    // Placement decides speed only: results do not depend on which workgroup computes what.
+    int group = (bid & 7) + 8 * (jb >> 4);
+    int within = jb & 15;
+    int member = (dp.mapmode & 1) ? (within >> 1) : (within & 7);
+    int role = (dp.mapmode & 1) ? (within & 1) : (within >> 3);
+    if (dp.mapmode & 2) {
+        if (tid == 0) {
+            const int xsl = bid & 7;
+            const int nwg = xsl < dp.ngroups ? 16 * ((dp.ngroups - xsl + 7) / 8) : 0;       // workgroups of this slot that have work
+            unsigned* cen = reinterpret_cast<unsigned*>(ws) + dp.oCen + xsl * 520;      // [0] arrived, [1] CUs seen, [8..263] workgroups per CU, [264..519] rank + 1 per CU
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            const unsigned key = (hw >> 8) & 0xffu;
+            int ok = 0, rank = 0, sl = 0;
+            if (group < dp.ngroups) {
+                sl = (int)atomicAdd(cen + 8 + key, 1u);
+                if (sl == 0) { rank = (int)atomicAdd(cen + 1, 1u); __hip_atomic_store(cen + 264 + key, (unsigned)rank + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                atomicAdd(cen + 0, 1u);
+                int spins = 0;
+                while ((int)__hip_atomic_load(cen + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > dp.spin_max) { atomicExch(reinterpret_cast<unsigned*>(ws) + dp.oErr, 0x3000u + DUK_XCC); break; }
+                }
+                ok = spins <= dp.spin_max && (int)__hip_atomic_load(cen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 2 == nwg;
+                if (ok && sl != 0) {
+                    spins = 0;
+                    unsigned r1 = 0;
+                    while ((r1 = __hip_atomic_load(cen + 264 + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > dp.spin_max) { atomicExch(reinterpret_cast<unsigned*>(ws) + dp.oErr, 0x3000u + DUK_XCC); r1 = 1u; break; }
+                    }
+                    rank = (int)r1 - 1;
+                }
+            }
+            if (ok) atomicAdd(reinterpret_cast<unsigned*>(ws) + dp.oErr + 1, 1u);       // (observability: NOCF_DEBUG=2 prints how many workgroups took the census map)
+            lds[0] = (float)ok; lds[1] = (float)rank; lds[2] = (float)sl;
+        }
+        __syncthreads();
+        if (lds[0] != 0.f) {
+            const int rank = (int)lds[1];
+            group = (bid & 7) + 8 * (rank >> 3);
+            member = rank & 7;
+            role = (int)lds[2];
+            within = member * 2 + role;
+        }
+        __syncthreads();
+    }
     if (group >= dp.ngroups) return;
-    const int within = jb & 15;
-    const int member = dp.mapmode ? (within >> 1) : (within & 7);
-    const int role = dp.mapmode ? (within & 1) : (within >> 3);
-    const int tid = threadIdx.x, lane = tid & 63, slot = lane >> 4;
+    const int lane = tid & 63, slot = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int NT = dp.NT; DU_PIN(NT);
     const int d = dp.d;
@@ -521,7 +570,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 
         // the owner's step, state part: gradient of evaluation e-1 -> RK update -> stage state of evaluation e published.
         // Leaves this lane's share of sum p^2 (q0) and its candidate for dPhi/dt (gdv) for the cost part.
-        auto own_state = [&](int s, int e, float hs, int pst, float t_pub, bool have, u32x4 (&pv)[DU_G], float& q0, float& gdv) {
+        auto own_state = [&](int s, int e, float hs, int pst, float t_pub, bool have, u32x4 (&pv)[DU_G], float& q0, float& gdv, unsigned& qa, unsigned& qb) {
             const int t = s >> 1, j = s & 1;
             const int parG = (e - 1) & 1, parS = e & 1;
             const bool rk_last = (pst == nstage - 1);
@@ -530,7 +579,12 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             const int sbase = DA_T + s * DS_STRIDE;
             DTL(40 * t + 0);
             const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2];      // (in flight while the partials are polled)
-            const f32x4 gs = gather_g(s, parG, have, pv);
+            if (!have) g_request(s, parG, pv);
+            {   // the cost scalars of this sample ride along (consumed by own_costs, behind P1): their round trip is off the critical path
+                const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((parG * NT + t) * DU_G + member) * 4 + 2 * j) * 4, 16);
+                qa = v2[0]; qb = v2[1];
+            }
+            const f32x4 gs = gather_g(s, parG, true, pv);
             DTL(40 * t + 1);
             q0 = 0.f;
 #pragma unroll
@@ -688,9 +742,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     const int s0 = 2 * t, s1 = 2 * t + 1;
                     const int sown = ((s0 & 3) == wave) ? s0 : (((s1 & 3) == wave) ? s1 : -1);      // this wave's own sample of the tile, if any
                     float cq0 = 0.f, cgd = 0.f;
-                    const bool pf_have = pf_s == sown && sown >= 0;                 // the partials were requested in front of the previous P2
-                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, (float)te, pf_have, pf, cq0, cgd);
-                    const unsigned qa_ = pf_qa, qb_ = pf_qb;
+                    const bool pf_have = DU_PREFETCH_G && pf_s == sown && sown >= 0;                 // the partials were requested in front of the previous P2
+                    unsigned qa_ = 0, qb_ = 0;
+                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, (float)te, pf_have, pf, cq0, cgd, qa_, qb_);
                     pf_s = -1;
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
@@ -713,10 +767,15 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         du_st_sent(g, vb, xV + fr);                 // (V one phase early: header, H1)
                     }
                     DTL(40 * t + 7);
+#ifdef NOCF_STAMPS
+                    if (dp.dbg & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DTL(40 * t + 18); }      // how long do the five stores take to be acknowledged?
+#endif
                     // (in the shadow of the u0 exchange) the cost integrals of the previous evaluation; z = A s, A^T z + c of the own sample
+                    // (the owner of a sample integrates its costs; the wave two places on -- it owns nothing of this tile -- does the z work)
                     if (sown >= 0) {
-                        if (e > 1) own_costs(sown, e, p_hs, p_st, cq0, cgd, pf_have, qa_, qb_);
-                        azc_step(sown, fin);
+                        if (e > 1) own_costs(sown, e, p_hs, p_st, cq0, cgd, true, qa_, qb_);
+                    } else {
+                        azc_step((s0 & 3) == (wave ^ 2) ? s0 : s1, fin);
                     }
                     DTL(40 * t + 8);
                     // With several tiles per group the partial gradients of the NEXT tile's own sample have usually arrived by now (role B
@@ -827,6 +886,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         __syncthreads();
         const DXPar xp = du_x_params(pb, PD);
         const int E = ra.nt * nstage + 1;
+        u32x4 spf = {0u, 0u, 0u, 0u};                              // prefetched own-state piece of tile spf_t (-1: none)
+        int spf_t = -1;
         for (int e = 1; e <= E; ++e) {
             const bool fin = (e == E);
             const int par = e & 1;
@@ -838,21 +899,34 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     if (wave < 2) {                                     // 80 pieces of 16 B: dims 4 l .. 4 l + 3 of own sample j
                         const int p = tid < 80 ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, mt = r_ >> 2, sl = r_ & 3;
                         const int off = xS + ((par * NT + t) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16;
-                        u32x4 v;
+                        u32x4 v = spf;
+                        bool have = spf_t == t;                         // requested before the previous tile's P4 stores (see there)
                         int spins = 0;
                         while (true) {
-                            v = du_ld(g, off, 0);
+                            if (!have) v = du_ld(g, off, 0);
+                            have = false;
                             if (!__any(du_bad(v))) break;
                             if (du_spin(g, spins, DUK_S)) break;
                         }
+                        spf_t = -1;
                         const f32x4 f = du_f(v);
-                        if (tid < 80) L4[(DB_XB + j * DU_DP + 4 * r_) >> 2] = make_float4(f[0], f[1], f[2], f[3]);
+                        if (tid < 80) {                                 // scatter into the [entry][4] layout, every agent twice (entries i and i + N)
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const int i = 4 * r_ + e4;
+                                if (i < d) {
+                                    const int ag = i / PD, k = i - PD * ag;
+                                    lds[DB_XA + (j * 128 + ag) * 4 + k] = f[e4];
+                                    lds[DB_XA + (j * 128 + ag + xp.N) * 4 + k] = f[e4];
+                                }
+                            }
+                        }
                     }
                     __syncthreads();
                     DTL(40 * t + 21);
                     {
                         float q_ = 0.f, w_ = 0.f;
-                        du_x_wave<PD>(pb, xp, DB_XB + (wave & 1) * DU_DP, lane, wave >> 1, q_, w_);
+                        du_x_wave<PD>(pb, xp, (DB_XA >> 2) + (wave & 1) * 128, lane, wave >> 1, q_, w_);
                         q_ = sum64(q_); w_ = sum64(w_);
                         if (lane == 0) { lds[DB_XP + 2 * wave] = q_; lds[DB_XP + 2 * wave + 1] = w_; }
                     }
@@ -911,6 +985,16 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 DTL(40 * t + 27);
                 __syncthreads();
                 DTL(40 * t + 28);
+                // the own-state pieces of the NEXT tile's cost pass: requested here, in front of P4 and its stores (a load issued behind
+                // a store is not answered before the store is: vmcnt retires in order), consumed at the next tile's entry
+                if (wave < 2 && !fin) {
+                    const int tn = (t + 1 < NT) ? t + 1 : 0, pn = (t + 1 < NT) ? par : (par ^ 1);
+                    if (!(t + 1 >= NT && e + 1 == E)) {
+                        const int p = tid < 80 ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, mt = r_ >> 2, sl = r_ & 3;
+                        spf = du_ld(g, xS + ((pn * NT + tn) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16, 0);
+                        spf_t = tn;
+                    }
+                }
                 // ================= P4: partial g = K0[H_c,:]^T y for the dim tiles wave, wave+4, wave+8 =================
                 const int gP = xG + (((par * NT + t) * DU_G + member) * DU_KBD) * 1024;
                 {
@@ -973,6 +1057,7 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
     dp.oPlan = o; o += 256;
     dp.oErr = o; o += 64;                                                          // (uint index == float index)
     dp.oXcc = o; o += 32 * 16;
+    dp.oCen = o; o += 8 * 520;                                                    // CU census of the role map (uints)
     const long nW = (long)DU_G * 4 * DU_KBM * 64, nK1 = (long)DU_G * 4 * DU_KBD * 64, nK4 = (long)DU_G * DU_KBD * 4 * 64;   // float4s
     dp.oW2 = o / 4; o += nW * 4;
     dp.oW3 = o / 4; o += nW * 4;
@@ -1033,12 +1118,12 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
         if (rc) return rc;
         dp.cb = phi->cb;
         dp.fast = du_env_int("NOCF_DUO_FAST", 1);
-        dp.mapmode = du_env_int("NOCF_DUO_MAP", 0);
+        dp.mapmode = du_env_int("NOCF_DUO_MAP", 3);                 // bit 0: A / B of a member adjacent in the static map; bit 1: CU census (see the kernel)
         dp.dbg = du_env_int("NOCF_DUO_DBG", 0);
         dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
         hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws);     // (every chunk: the plan record changes with the chunk's rows)
         if (r0 == 0) { e = hipMemsetAsync(ws + dp.oErr, 0, 64 * 4, st); if (e) return (int)e; }
-        e = hipMemsetAsync(ws + dp.oXcc, 0, 32 * 16 * 4, st); if (e) return (int)e;
+        e = hipMemsetAsync(ws + dp.oXcc, 0, (32 * 16 + 8 * 520) * 4, st); if (e) return (int)e;      // XCC table + CU census
         e = hipMemsetAsync(ws + dp.oX, 0xFF, (size_t)dp.ngroups * dp.xStride * 4, st);            // every exchange word starts as the sentinel
         if (e) return (int)e;
         RollArgs ra = ra_in;
@@ -1055,6 +1140,12 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
         e = hipLaunchKernel(fk, dim3(128 * ((dp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st);
         if (e) return (int)e;
         if (ev1 && r0 + chunk >= ra_in.n) (void)hipEventRecord(ev1, st);
+        if (debug >= 2) {
+            unsigned w[2] = {0, 0};
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(w, ws + dp.oErr, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[nocf] duo kernel: error word 0x%x, %u of %d workgroups paired by the CU census\n", w[0], w[1], 16 * dp.ngroups);
+        }
     }
     *errp = reinterpret_cast<const unsigned*>(ws) + dp0.oErr;
     return 0;

@@ -61,7 +61,8 @@ def main():
             keep = ~off
             md = max(abs(duo[keep, j].double().mean().item() - tile[keep, j].double().mean().item()) / (abs(tile[keep, j].double().mean().item()) + 1e-9)
                      for j in range(7)) if keep.any() else float("nan")
-            line = f"train={int(training)} n={n:5d} [{kd}] vs [{kt}]: rows off {int(off.sum())}, worst mean rel diff {md:.2e}, deterministic {torch.equal(duo, duo2)}, nan {int(torch.isnan(duo).sum())}"
+            cols = [abs(duo[keep, j].double().mean().item() - tile[keep, j].double().mean().item()) / (abs(tile[keep, j].double().mean().item()) + 1e-9) for j in range(7)] if keep.any() else []
+            line = f"train={int(training)} n={n:5d} [{kd}] vs [{kt}]: rows off {int(off.sum())}, worst mean rel diff {md:.2e} (cols {' '.join('%.1e' % c for c in cols)}), deterministic {torch.equal(duo, duo2)}, nan {int(torch.isnan(duo).sum())}"
             if not training:
                 setenv()
                 t_duo = timeit(x, net, prob, nt, m["alph"])
