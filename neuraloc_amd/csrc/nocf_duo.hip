@@ -250,6 +250,27 @@ __device__ __forceinline__ void du_gather(DCtx& g, int wave, int lane, int sbyte
         if (NF % 4 == 0 || wave + 4 * u < NF) { const f32x4 f = du_f(v[u]); L4[l4 + (wave + 4 * u) * 64 + lane] = make_float4(f[0], f[1], f[2], f[3]); }
 }
 
+// The same with the NF fragments split over TWO waves (which = 0 / 1 takes the even / odd ones).
+template <int NF>
+__device__ __forceinline__ void du_gather2(DCtx& g, int which, int lane, int sbyte, int l4, unsigned what) {
+    constexpr int NFW = (NF + 1) / 2;
+    u32x4 v[NFW];
+    int spins = 0;
+    while (true) {
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) v[u] = du_ld(g, lane * 16, sbyte + (which + 2 * u) * 1024);
+#pragma unroll
+        for (int u = 0; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) bad |= du_bad(v[u]);
+        if (!__any(bad)) break;
+        if (du_spin(g, spins, what)) break;
+    }
+    float4* L4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int u = 0; u < NFW; ++u)
+        if (NF % 2 == 0 || which + 2 * u < NF) { const f32x4 f = du_f(v[u]); L4[l4 + (which + 2 * u) * 64 + lane] = make_float4(f[0], f[1], f[2], f[3]); }
+}
+
 // acc = sum over NKB k-blocks of W[kb] (A operand: AccVGPRs if ACC, else VGPRs) x the staged fragments at LDS float4 index b4 + kb*64 (B operand).
 // Two accumulation chains (a dependent v_mfma_f32_16x16x4_f32 may issue 40 cycles behind its producer; the chains alternate
 // at 32), B fragments read 3 k-blocks (12 MFMAs = 384 cycles) ahead of their use.
@@ -748,7 +769,11 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     pf_s = -1;
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
-                    du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
+                    // (the two waves that own nothing of this tile fetch the stage states: the owners have just stored theirs, and a load issued
+                    // behind a store is not answered before the store has been acknowledged -- vmcnt retires in order -- which occasionally
+                    // takes thousands of cycles that every member of the group then waits for: 5.54 -> 5.29 ms)
+                    if (e > 1) { if (sown < 0) du_gather2<DU_KBD>(g, (wave ^ (wave >> 1)) & 1, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S); }
+                    else du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
                     __syncthreads();
                     DTL(40 * t + 5);
                     {
