@@ -86,6 +86,7 @@ def main(argv=None):
             for _ in range(reps):
                 na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph)
             torch.cuda.synchronize()
+            na.check_errors()
             dt = (time.time() - t0) / reps
             print("%s time: %5f   avg time / RK4 timestep: %5f   trajectories/s: %.1f" % (name, dt, dt / nt, x.shape[0] / dt))
         if args.make_vid:

@@ -91,9 +91,17 @@ typedef struct NocfProb {
 int nocf_version(void);
 
 /* measurement hook: name of the rollout kernel the last nocf_rollout_f32 / nocf_rollout_record_f32 call of this process
- * launched ("rollout_slab_kernel", "rollout_kernel<shape-specialised>", "rollout_kernel<generic>", "rollout_lane_kernel",
- * "rollout_group_kernel", or "none"); a static string, not thread-safe (bench.py labels its roofline with it) */
+ * launched ("rollout_duo_kernel", "rollout_mono_kernel", "rollout_kernel<shape-specialised>", "rollout_kernel<generic>",
+ * "rollout_lane_kernel", or "none"); a static string, not thread-safe (bench.py labels its roofline with it) */
 const char* nocf_last_rollout_kernel(void);
+
+/* Asynchronous status of the last nocf_rollout_f32 / nocf_rollout_record_f32 call of this process.  The split-role kernel's
+ * workgroups wait for each other with bounded polls; when one times out (the GPU was shared with another kernel, so that not all
+ * workgroups were resident) the kernel sets an error word, finishes, and every output row and mean is NaN.  This call enqueues a
+ * 4-byte device-to-host copy of that word into `host_word` (pinned host memory) on `stream`; once the stream has reached it,
+ * *host_word != 0 means the rollout failed (0x3000 + the exchange kind that timed out).  Returns 1 when a copy was enqueued, 0 when
+ * the last rollout kernel has no such word (*host_word is set to 0), or an error code.  The Python layer raises RuntimeError from it. */
+int nocf_last_rollout_status_async(uint32_t* host_word, void* stream);
 
 /* bytes of scratch `workspace` a call with these shapes needs (packed weight images) */
 size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh);

@@ -79,6 +79,7 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
     if len(alph) < 6:
         raise ValueError("alph needs 6 entries")
     Phi._guard_no_autograd(x, "OCflow")
+    _lib.check_errors()                                    # a failed earlier rollout whose status has arrived raises here
     phi_st, keep1, ws = Phi._c_struct(n)
     prob_st, keep2 = prob._c_struct(x.device)
     dev = x.device
@@ -98,6 +99,7 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
                                          _lib.ptr(zFull), _lib.ptr(ctrlFull),
                                          _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "nocf_rollout_f32")
+    _lib.track_rollout_status(L, dev, "OCflow")
     return persample, sums, zFull, ctrlFull
 
 

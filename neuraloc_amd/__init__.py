@@ -6,6 +6,7 @@ from .OCflow import OCflow, ocG
 from .problem import Cross2D, SwarmTraj, Quadcopter
 from .initProb import initProb, resample
 from .distributed import OCflow_sharded, shard_rows, reduce_cost_sums
+from ._lib import check_errors
 
 __all__ = ["Phi", "ResNN", "antiderivTanh", "derivTanh", "OCflow", "ocG", "Cross2D", "SwarmTraj",
-           "Quadcopter", "initProb", "resample", "OCflow_sharded", "shard_rows", "reduce_cost_sums"]
+           "Quadcopter", "initProb", "resample", "OCflow_sharded", "shard_rows", "reduce_cost_sums", "check_errors"]

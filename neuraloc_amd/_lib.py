@@ -157,11 +157,58 @@ def _bind(L):
     L.nocf_prob_eval_f64.argtypes = [C.POINTER(NocfProb64), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.nocf_phi_f64.restype = C.c_int
     L.nocf_phi_f64.argtypes = [C.POINTER(NocfPhi64), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.nocf_last_rollout_status_async.restype = C.c_int
+    L.nocf_last_rollout_status_async.argtypes = [C.c_void_p, C.c_void_p]
     L.nocf_debug_set_stamp_buffer.restype = C.c_int
     L.nocf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     L.nocf_selftest_mfma.restype = C.c_int
     L.nocf_selftest_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     return L
+
+
+# ---- asynchronous rollout status (include/nocf.h: nocf_last_rollout_status_async).  The split-role kernel reports a timed-out
+# exchange through an error word; its copy is enqueued behind every rollout and looked at WITHOUT synchronising: at the next call
+# into this package, in check_errors() (neuraloc_amd.check_errors: what a driver calls after it has synchronised anyway), or
+# when the status has already arrived.  A failed rollout's outputs are NaN in any case.
+_pending = []          # [event, pinned host word, description]
+_free_words = []
+
+
+def track_rollout_status(L, device, what):
+    word = _free_words.pop() if _free_words else torch.zeros(1, dtype=torch.int32).pin_memory()
+    rc = L.nocf_last_rollout_status_async(C.c_void_p(word.data_ptr()), stream_ptr(device))
+    if rc == 1:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        _pending.append((ev, word, what))
+    else:
+        _free_words.append(word)
+        if rc != 0:
+            check(rc, "nocf_last_rollout_status_async")
+
+
+def check_errors(sync=False):
+    """Raise RuntimeError if a rollout whose status has arrived (sync=True: of every rollout launched so far, after waiting for it)
+    reported a timed-out exchange.  Called at the start of every call into the package; call it with sync=True where results are
+    consumed on the host."""
+    while _pending:
+        ev, word, what = _pending[0]
+        if sync:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        _pending.pop(0)
+        code = int(word[0])
+        word[0] = 0
+        _free_words.append(word)
+        if code != 0:
+            for _e, w, _w in _pending:
+                _free_words.append(w)
+            _pending.clear()
+            raise RuntimeError(f"{what}: the weight-stationary rollout kernel timed out waiting for another workgroup (error word "
+                               f"0x{code:x}); its outputs are NaN.  The kernel needs the whole GPU: all of its workgroups must be resident at "
+                               "once, so nothing else may run on the device while it does (another stream or process took compute units), "
+                               "or set NOCF_DUO=0 to use the per-tile kernel")
 
 
 def check(rc, what):

@@ -784,12 +784,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         f32x4 sg, th;
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) { float s_, t_; act_pair(acc[e4] + b0v[e4], s_, t_); sg[e4] = s_; th[e4] = t_; }
-                        const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, fr = (((par ^ 1) * NT + t) * DU_KBM + 4 * member + wave) * 1024;
+                        const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
                         du_st(g, vb, xU + fo, sg);
                         du_st(g, vb, xT + fo, th);
-                        du_st_sent(g, vb, xU + fr);
-                        du_st_sent(g, vb, xT + fr);
-                        du_st_sent(g, vb, xV + fr);                 // (V one phase early: header, H1)
                     }
                     DTL(40 * t + 7);
 #ifdef NOCF_STAMPS
@@ -822,8 +819,16 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     __syncthreads();
                     DTL(40 * t + 10);
                     {
+                        // the slots of the previous evaluation (every reader is done: S of this evaluation exists).  Here, not in the P1
+                        // epilogue: no load of this wave waits behind them, and the GEMM covers their acknowledgement (V one phase early:
+                        // header, H1)
+                        const int fr = (((par ^ 1) * NT + t) * DU_KBM + 4 * member + wave) * 1024;
+                        du_st_sent(g, vb, xU + fr);
+                        du_st_sent(g, vb, xT + fr);
+                        du_st_sent(g, vb, xV + fr);
                         const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DA_UF >> 2) + lane);
                         DTL(40 * t + 11);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the resets are acknowledged -- long ago -- before V is stored: header, H1)
                         const float4 b1s = L4[((DA_VEC + 64) >> 2) + 4 * wave + slot], wvs = L4[((DA_VEC + 128) >> 2) + 4 * wave + slot];
                         const float b1v[4] = {b1s.x, b1s.y, b1s.z, b1s.w}, wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
                         f32x4 v;

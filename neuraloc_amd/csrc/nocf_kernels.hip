@@ -1360,7 +1360,7 @@ __global__ void __launch_bounds__(512) prob_kernel(DevPlan pl, DevProb pb, const
 }
 
 // deterministic reduction of the per-sample table: 7 column sums (fp64 accumulation, fixed order) + n
-__global__ void __launch_bounds__(256) cost_sum_kernel(const float* __restrict__ tab, long n, float* __restrict__ out,
+__global__ void __launch_bounds__(256) cost_sum_kernel(float* __restrict__ tab, long n, float* __restrict__ out,
                                                        const unsigned* __restrict__ err) {
     __shared__ double sh[256 * 7];
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1374,8 +1374,11 @@ __global__ void __launch_bounds__(256) cost_sum_kernel(const float* __restrict__
         __syncthreads();
     }
     if (threadIdx.x < 7) out[threadIdx.x] = (float)sh[threadIdx.x];
-    // a timed-out exchange in the group kernel must not pass as a result: poison the count -> every mean is NaN
-    if (threadIdx.x == 7) out[7] = (err && *err) ? __int_as_float(0x7fc00000) : (float)n;
+    // a timed-out exchange in the split-role kernel must not pass as a result: poison the count (every mean is NaN) and every
+    // per-sample row (the noMean path returns them); the host raises when it reads the error word (nocf_last_rollout_status_async)
+    const bool failed = err && *err;
+    if (threadIdx.x == 7) out[7] = failed ? __int_as_float(0x7fc00000) : (float)n;
+    if (failed) for (long i = threadIdx.x; i < n * 7; i += 256) tab[i] = __int_as_float(0x7fc00000);
 }
 
 // means of the 7 cost terms and Jc from the 8 sums, one launch instead of a dozen tiny elementwise ones
@@ -1489,21 +1492,11 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
     for (int q = 0; q < 4; ++q) out[q * 64 + lane] = acc[q];
 }
 
-#include "nocf_group.inc"
-#include "nocf_slab.inc"
 #include "nocf_mono.inc"
 #include "nocf_f64.inc"
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
 #include "nocf_lane_bwd.inc"
-
-__global__ void store_group_plan_kernel(GroupPlan gp, float* ws, const float* cbp) {
-    if (threadIdx.x < sizeof(GroupPlan) / 4) {
-        unsigned v = reinterpret_cast<const unsigned*>(&gp)[threadIdx.x];
-        if (cbp && threadIdx.x == (offsetof(GroupPlan, pp) + offsetof(DevPlan, cb)) / 4) v = __float_as_uint(*cbp);
-        reinterpret_cast<unsigned*>(ws + gp.pp.oPlan)[threadIdx.x] = v;
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // host side: plan construction and the C ABI
@@ -1521,131 +1514,6 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, i
     const int diagHalf = 0;
 #endif
     return plan_layout(d, m, nTh, r, n_agents, bwd, env_int("NOCF_NWAVES", 0), env_int("NOCF_SUBTILES", 0), diagHalf, *out);
-}
-
-// Group (weight-sliced) plan: returns 0 and fills *out when the shape qualifies, else an NOCF_E_* code.
-static int make_group_plan(const DevPlan& base, int n_agents, int kind /* NOCF_PROB_* or -1 */, long n, GroupPlan* out) {
-    GroupPlan gp;
-    memset(&gp, 0, sizeof(gp));
-    gp.pp = base;
-    DevPlan& pl = gp.pp;
-    const int G = base.MB;
-    if (!(G == 2 || G == 4 || G == 8 || G == 16) || base.DB > 4) return NOCF_E_SHAPE;
-    gp.G = G; gp.OWN = GK_TG / G; gp.L = base.nTh - 1;
-    pl.T = gp.OWN; pl.nwaves = 4;
-    gp.LDg = rup(std::max(base.KQm * 4, base.m), 64) + 4;
-    gp.LDy = 68;
-    const int L = gp.L, TG = GK_TG, OWN = gp.OWN;
-    (void)n_agents;
-    int l = 0;
-    auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
-    gp.lR1 = take(std::max(TG * base.LDs, 4 * TG * 64));
-    gp.lUV = take(std::max(TG * gp.LDg, 4 * TG * 64));      // also hosts the opening phase's partial slots
-    gp.lGT = take(L * TG * 64);
-    gp.lAVo = take(TG * 64);
-    gp.lUo = take((L > 1 ? 2 : 1) * TG * 64);
-    gp.lYo = take(TG * gp.LDy + 32);
-    gp.lVO = take((L + 2) * 64);
-    gp.lCW = take(base.DB * 64);
-    pl.lSB = take(OWN * base.LDs);
-    pl.lG = take(OWN * base.GLD);
-    pl.lZQ = take(OWN * ZQLD);
-    pl.lZ0 = take(OWN * base.ZLD); pl.lZA = take(OWN * base.ZLD); pl.lDZ = take(OWN * base.ZLD);
-    pl.lRED = take(std::max(OWN, 4) * 4);
-    pl.lSC = take(OWN * std::max(1, n_agents) + 8);
-    pl.lPHI = take(OWN);
-    const bool maybe_quad = (kind < 0 || kind == NOCF_PROB_QUADCOPTER);
-    pl.lTRIG = take(maybe_quad ? OWN * std::max(1, n_agents) * 6 : 4);
-    pl.lPT = take(4);
-    take(64);
-    pl.ldsFloats = l;
-    if ((size_t)l * 4 > 80 * 1024) return NOCF_E_LDS;          // two workgroups per CU must fit
-    // exchange regions and flags behind the plan record
-    gp.ngroups = (int)((n + TG - 1) / TG);
-    gp.nKinds = 2 * L + 2;
-    gp.SLDx = base.KQ1 * 4;
-    int x = 0;
-    auto xt = [&](int nfl) { int o = x; x += rup(nfl, 64); return o; };
-    gp.xS = xt(TG * gp.SLDx);
-    gp.xHstride = rup(TG * base.m, 64);
-    gp.xH = xt(2 * L * gp.xHstride);
-    gp.xG = xt(G * TG * base.GLD);
-    gp.xP = xt(G * TG);
-    gp.xStride = x;
-    long o = base.oPlan + (long)rup((int)(sizeof(GroupPlan) / 4), 64);
-    gp.oFlags = o; o += rup(gp.ngroups * gp.nKinds * G, 64);
-    gp.oErr = o; o += 64;
-    gp.oX = o;
-    *out = gp;
-    return 0;
-}
-
-static size_t group_ws_bytes(const GroupPlan& gp) {
-    return (size_t)(gp.oX + (long)gp.ngroups * gp.xStride) * sizeof(float);
-}
-
-// Slab (weight-stationary) plan: returns 0 and fills *out when the shape qualifies, else an NOCF_E_* code.
-static int make_slab_plan(const DevPlan& base, int n_agents, long n, SlabPlan* out) {
-    if (base.nTh != 2 || base.m != 64 * SL_G || base.D1 > 16 * SL_KBD || base.r > 16 || n < 1 || n_agents > 64) return NOCF_E_SHAPE;
-    SlabPlan sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.pp = base;
-    DevPlan& pl = sp.pp;
-    const int NT = n > 16 * 32 ? 2 : 1, OWN = 2 * NT;
-    sp.NT = NT; sp.OWN = OWN;
-    sp.ngroups = (int)((n + 16 * NT - 1) / (16 * NT));
-    if (sp.ngroups > 32) return NOCF_E_SHAPE;                    // all workgroups must be resident at once (one per CU)
-    pl.T = OWN; pl.nwaves = 4;
-    int l = 0;
-    auto take = [&](int nfl) { int o = l; l += rup(nfl, 4); return o; };
-    sp.lUF = take(NT * SL_KBM * 256);
-    sp.lSF = take(NT * SL_KBD * 256);
-    sp.lK4 = take(SL_KBD * 4 * 256);
-    sp.lYF = take(NT * 4 * 256);
-    sp.lVO = take(192);
-    sp.lCW = take(16 * SL_KBD);
-    sp.lA = take(SL_KBD * 256);
-    sp.lXN = take(OWN * base.ZLD);
-    sp.lPHIP = take(NT * 64);
-    pl.lSB = take(OWN * base.LDs);
-    pl.lG = take(OWN * base.GLD);
-    pl.lZQ = take(OWN * ZQLD);
-    pl.lZ0 = take(OWN * base.ZLD);
-    pl.lZA = take(OWN * base.ZLD);
-    pl.lDZ = pl.lZA;                                             // quadcopter only (never takes this kernel)
-    pl.lRED = take(64);
-    pl.lSC = take(OWN * std::max(1, n_agents) + 8);
-    pl.lPHI = take(4);
-    pl.lTRIG = take(4);
-    pl.lPT = take(4);
-    pl.lPW = take(2 * OWN);
-    pl.ldsFloats = l;
-    if ((size_t)l * 4 > 160 * 1024) return NOCF_E_LDS;
-    long o = base.oPlan + (long)rup((int)(sizeof(SlabPlan) / 4), 64);         // floats
-    const long nW = (long)SL_G * 4 * SL_KBM * 64, nK1 = (long)SL_G * 4 * SL_KBD * 64, nK4 = (long)SL_G * SL_KBD * 4 * 64;   // float4s
-    sp.oW2 = o / 4; o += nW * 4;
-    sp.oW3 = o / 4; o += nW * 4;
-    sp.oK1 = o / 4; o += nK1 * 4;
-    sp.oK4 = o / 4; o += nK4 * 4;
-    sp.oAZ = o / 4; o += (long)SL_KBD * 64 * 4;
-    sp.oFlags = o; o += 64;
-    sp.oErr = o; o += 64;
-    sp.oXcc = o; o += rup(sp.ngroups * SL_G, 64);
-    int x = 0;
-    auto xt = [&](int nfl) { int oo = x; x += rup(nfl, 64); return oo; };
-    sp.xU = xt(2 * NT * SL_KBM * 256);                          // [parity][tile][k-block] fragments
-    sp.xV = xt(2 * NT * SL_KBM * 256);
-    sp.xG = xt(2 * NT * SL_G * SL_KBD * 256);                   // [parity][tile][member][dim tile]
-    sp.xS = xt(2 * NT * SL_KBD * 256);
-    sp.xP = xt(NT * SL_G * 16);
-    sp.xStride = x;
-    sp.oX = o;
-    *out = sp;
-    return 0;
-}
-
-static size_t slab_ws_bytes(const SlabPlan& sp) {
-    return (size_t)(sp.oX + (long)sp.ngroups * sp.xStride) * sizeof(float);
 }
 
 // Mono (one-CU weight-stationary) plan: returns 0 and fills *out when the shape has an instantiation, else an NOCF_E_* code.
@@ -1757,6 +1625,7 @@ static int check_phi(const NocfPhi* phi) {
 
 // ---- optional in-library timing of the rollout kernel (bench.py): HIP events recorded on the
 // launch stream immediately around the kernel, so the figure is the kernel's own duration.
+static const unsigned* g_last_errp = nullptr;         // device address of the last rollout's error word (split-role kernel), or null
 static const char* g_last_kernel = "none";           // measurement hook: which rollout kernel the last call launched (nocf_last_rollout_kernel)
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static bool g_prof_on = false;
@@ -1767,6 +1636,13 @@ extern "C" {
 int nocf_version(void) { return NOCF_VERSION; }
 
 const char* nocf_last_rollout_kernel(void) { return g_last_kernel; }
+
+int nocf_last_rollout_status_async(uint32_t* host_word, void* stream) {
+    if (!host_word) return NOCF_E_NULL;
+    if (!g_last_errp) { *host_word = 0u; return 0; }
+    const hipError_t e = hipMemcpyAsync(host_word, g_last_errp, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return e ? (int)e : 1;
+}
 
 int nocf_debug_set_stamp_buffer(void* device_buf) {
 #ifdef NOCF_STAMPS
@@ -1904,10 +1780,6 @@ size_t nocf_rollout_workspace_bytes(int32_t d, int32_t m, int32_t nTh, int64_t n
     const int r = std::min(10, d + 1);
     if (make_plan(d, m, nTh, r, 1, &pl) != 0) return 0;
     size_t b = plan_ws_bytes(pl);
-    GroupPlan gp;
-    if (n > 0 && make_group_plan(pl, 1, NOCF_PROB_QUADCOPTER, n, &gp) == 0) b = std::max(b, group_ws_bytes(gp));   // LDS-lightest view; sizes of the exchange area do not depend on the problem
-    SlabPlan sp;
-    if (n > 0 && make_slab_plan(pl, 1, std::min<long>(n, 1024), &sp) == 0) b = std::max(b, slab_ws_bytes(sp));
     MonoPlan mpl;
     if (make_mono_plan(pl, 1, &mpl) == 0) b = std::max(b, mono_ws_bytes(mpl));
 #ifndef NOCF_JIT_ONLY
@@ -1953,6 +1825,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     hipError_t e;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const unsigned* errp = nullptr;
+    g_last_errp = nullptr;
     // small networks: one wave per sample, everything in registers (nocf_lane.inc); needs no packed images
     const bool lane_ok = env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&
                          pb.kind != NOCF_PROB_QUADCOPTER && pb.nAgents <= 16 && !g_stamp_buf;
@@ -1986,13 +1859,14 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
 #ifndef NOCF_JIT_ONLY
     // split-role weight-stationary kernel (nocf_duo.hip): wide two-layer networks (m = 512) on point-agent problems, any batch
     // size (chunks of 2048 rows), evaluation and the recording forward of training
-    if (env_int("NOCF_DUO", 1) != 0 && !(env_int("NOCF_GROUP", 0) != 0) && !(env_int("NOCF_SLAB", 1) >= 2)) {
+    if (env_int("NOCF_DUO", 1) != 0) {
         if (g_prof_on) {
             if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
         }
         rc = duo_launch(phi, pb, ra, ws, workspace_bytes, st, &errp, env_int("NOCF_DEBUG", 0), g_prof_on ? ev0 : nullptr, g_prof_on ? ev1 : nullptr);
         if (rc == 0) {
             g_last_kernel = "rollout_duo_kernel";
+            g_last_errp = errp;
             if (g_prof_on) g_prof_events.emplace_back(ev0, ev1);
             if (cost_sums) {
                 hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
@@ -2008,20 +1882,10 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     rc = pack_weights(pl, phi, ws, st);
     if (rc) return rc;
     const DevPlan* plp = reinterpret_cast<const DevPlan*>(ws + pl.oPlan);
-    // weight-sliced group kernel: when the hidden width spans 2..16 column blocks, the caller's workspace has
-    // room for the exchange buffers and every workgroup of the grid can be resident at once (2 per CU)
-    GroupPlan gp;
-    bool use_group = !s_all && env_int("NOCF_GROUP", 0) != 0 && make_group_plan(pl, pb.nAgents, pb.kind, n, &gp) == 0 &&
-                     workspace_bytes >= group_ws_bytes(gp);
-    if (use_group) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) use_group = false;
-        else if ((long)gp.ngroups * gp.G > 2L * cus) use_group = false;
-    }
     // one-CU weight-stationary kernel (nocf_mono.inc): two-layer networks of up to 128 hidden units whose shape has an
     // instantiation (singlequad): no weight stream, no inter-workgroup traffic; also with intermediates
     MonoPlan mpl;
-    const bool use_mono = !s_all && env_int("NOCF_MONO", 1) != 0 && !(env_int("NOCF_GROUP", 0) != 0) &&
+    const bool use_mono = !s_all && env_int("NOCF_MONO", 1) != 0 &&
                           make_mono_plan(pl, pb.nAgents, &mpl) == 0 && workspace_bytes >= mono_ws_bytes(mpl);
     if (use_mono) {
         mpl.pp.cb = phi->cb;
@@ -2052,68 +1916,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         }
         return 0;
     }
-    // weight-stationary slab kernel (nocf_slab.inc): wide two-layer networks on point-agent problems, plain rollouts of up
-    // to 1024 samples (32 groups x 8 workgroups, one workgroup per CU, all resident at once)
-    SlabPlan sp;
-    const int slab_knob = env_int("NOCF_SLAB", 1);
-    bool use_slab = !use_group && !zFull && slab_knob != 0 && (slab_knob >= 2 || n <= 1024) && pb.kind != NOCF_PROB_QUADCOPTER &&
-                    make_slab_plan(pl, pb.nAgents, n, &sp) == 0 && workspace_bytes >= slab_ws_bytes(sp);
-    if (use_slab) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) use_slab = false;
-        else if (64 * ((sp.ngroups + 7) / 8) > cus) use_slab = false;
-    }
-    if (use_slab) {
-        sp.pp.cb = phi->cb;
-        sp.fast = env_int("NOCF_SLAB_FAST", 1);
-        DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
-        hipLaunchKernelGGL(slab_pack_kernel, dim3(1024), dim3(256), 0, st, sp, P, ws);
-        e = hipMemsetAsync(ws + sp.oFlags, 0, (size_t)(sp.oX - sp.oFlags) * 4, st);            // error word, XCC id table
-        if (e) return (int)e;
-        e = hipMemsetAsync(ws + sp.oX, 0xFF, (size_t)sp.ngroups * sp.xStride * 4, st);         // every exchange word starts as the sentinel
-        if (e) return (int)e;
-        const size_t ldsBytes = (size_t)sp.pp.ldsFloats * 4;
-        const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
-        const void* fk = nullptr;
-#define NOCF_SLAB_PICK(NT_, PD_) if (sp.NT == NT_ && (c2 ? 2 : 3) == PD_) fk = s_all ? reinterpret_cast<const void*>(rollout_slab_kernel<NT_, PD_, true>) \
-                                                                                        : reinterpret_cast<const void*>(rollout_slab_kernel<NT_, PD_, false>);
-        NOCF_SLAB_PICK(1, 2) NOCF_SLAB_PICK(1, 3) NOCF_SLAB_PICK(2, 2) NOCF_SLAB_PICK(2, 3)
-#undef NOCF_SLAB_PICK
-        e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
-        if (env_int("NOCF_DEBUG", 0))
-            fprintf(stderr, "[nocf] slab kernel: %d groups x %d members, %d tile(s) of 16 samples, LDS %zu B/workgroup\n", sp.ngroups, SL_G, sp.NT, ldsBytes);
-        if (g_prof_on) {
-            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
-            (void)hipEventRecord(ev0, st);
-        }
-        const SlabPlan* spp = reinterpret_cast<const SlabPlan*>(ws + sp.pp.oPlan);
-        void* args[] = {(void*)&spp, (void*)&pb, (void*)&ws, (void*)&ra};
-        e = hipLaunchKernel(fk, dim3(64 * ((sp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st); if (e) return (int)e;
-        errp = reinterpret_cast<const unsigned*>(ws) + sp.oErr;
-        g_last_kernel = "rollout_slab_kernel";
-    } else if (use_group) {
-        gp.pp.cb = phi->cb;
-        hipLaunchKernelGGL(store_group_plan_kernel, dim3(1), dim3(256), 0, st, gp, ws, phi->cb_dev);
-        const size_t zbytes = (size_t)(gp.oX - gp.oFlags) * 4;                 // flags + error word
-        e = hipMemsetAsync(ws + gp.oFlags, 0, zbytes, st);
-        if (e) return (int)e;
-        const size_t ldsBytes = (size_t)gp.pp.ldsFloats * 4;
-        e = set_lds(rollout_group_kernel, ldsBytes); if (e) return (int)e;
-        if (env_int("NOCF_DEBUG", 0)) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_group_kernel, 256, ldsBytes);
-            fprintf(stderr, "[nocf] group kernel: %d groups x %d members, LDS %zu B/workgroup, occupancy API %d workgroups/CU\n",
-                    gp.ngroups, gp.G, ldsBytes, nb);
-        }
-        if (g_prof_on) {
-            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
-            (void)hipEventRecord(ev0, st);
-        }
-        hipLaunchKernelGGL(rollout_group_kernel, dim3(gp.ngroups * gp.G), dim3(256), ldsBytes, st,
-                           reinterpret_cast<const GroupPlan*>(ws + gp.pp.oPlan), pb, ws, ra);
-        errp = reinterpret_cast<const unsigned*>(ws) + gp.oErr;
-        g_last_kernel = "rollout_group_kernel";
-    } else {
+    {
         const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
         const int grid = (int)((n + pl.T - 1) / pl.T);
         const int block = pl.nwaves * 64;

@@ -92,13 +92,16 @@ class _OCflowTrain(torch.autograd.Function):
         z_out = torch.empty(n, d + 4, device=dev)
         s_all = torch.empty(nt * nstage, n, d + 1, device=dev)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+        _lib.check_errors()
         with torch.cuda.device(dev):
-            rc = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents).nocf_rollout_record_f32(
+            L = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+            rc = L.nocf_rollout_record_f32(
                                                     C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
                                                     float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
                                                     _lib.ptr(z_out), _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(s_all),
                                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_record_f32")
+        _lib.track_rollout_status(L, dev, "OCflow (training forward)")
         ctx.net, ctx.prob, ctx.tspan, ctx.nt, ctx.stepper, ctx.alph = net, prob, tspan, nt, stepper, list(alph)
         ctx.group = group
         if group is not None:

@@ -238,43 +238,6 @@ def test_error_behaviour():
     with torch.no_grad():
         na.OCflow(x, g_net, prob, [0.0, 1.0], 2)
     assert torch.equal(x, x0)                              # inputs are never mutated
-
-
-# ---- the experimental weight-sliced group kernel (NOCF_GROUP=1): same answers through a different decomposition
-@pytest.mark.parametrize("name", ["swarm50", "singlequad"])
-@pytest.mark.parametrize("tag", ["eval_rk4", "train_rk4", "eval_seg"])
-def test_group_kernel_matches_reference_golden(name, tag, monkeypatch):
-    from conftest import load_golden
-    g = load_golden(name)
-    monkeypatch.setenv("NOCF_GROUP", "1")
-    net = make_net(g, DEV)
-    prob = make_prob(g, DEV, training=tag.startswith("train"))
-    tspan = [float(v) for v in g[tag + "/tspan"]]
-    nt = int(g[tag + "/nt"])
-    alph = g.meta["alph"]
-    x = g.t("x").to(DEV)
-    with torch.no_grad():
-        Jc, cs = na.OCflow(x, net, prob, tspan, nt, "rk4", alph)
-        _, csn = na.OCflow(x, net, prob, tspan, nt, "rk4", alph, noMean=True)
-        zw = torch.from_numpy(g[tag + "/zFull"])
-        zF, cF = na.OCflow(x[:zw.shape[0]], net, prob, tspan, nt, "rk4", alph, intermediates=True)
-    assert torch.isfinite(Jc), "group kernel reported an exchange timeout (poisoned count)"
-    tab = torch.cat(csn, 1).cpu()
-    want = torch.from_numpy(g[tag + "/persample"])
-    off = (tab.double() - want.double()).abs() > 1e-3 + 1e-3 * want.double().abs()
-    flipped = off.any(dim=1)
-    assert int(flipped.sum()) <= 2
-    keep = ~flipped
-    for j in range(7):
-        mean_close(tab[keep, j].double().mean(), want[keep, j].double().mean(), f"{name} {tag} col {j}")
-    d = g.meta["d"]
-    bad, worst = count_off(zF.cpu()[:, :d], zw[:, :d], 1e-5, 1e-4)
-    assert bad == 0, f"{name} {tag}: {bad} state entries off (worst {worst:g})"
-    cw = torch.from_numpy(g[tag + "/ctrlFull"])
-    bad, worst = count_off(cF.cpu(), cw, 1e-4, 1e-4 * float(cw.abs().max()) + 1e-5)
-    assert bad == 0, f"{name} {tag}: {bad} control entries off (worst {worst:g})"
-
-
 def test_shock_rollout_matches_two_reference_style_segments(golden_pretrained):
     """the two-segment shocked rollout (src/plotter.py:815-824) against the oracle"""
     from neuraloc_amd.shock import shock_rollout

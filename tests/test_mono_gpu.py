@@ -95,7 +95,7 @@ def test_mono_intermediates_against_oracle_and_tile_kernel(monkeypatch):
 @pytest.mark.parametrize("training", [False, True])
 def test_mono_other_widths_against_oracle(m_, training):
     """quadcopter networks of other widths (hidden units zero-padded to 32 / 64 / 128 by the images)"""
-    from test_slab_gpu import _synth_state_dict
+    from util_hip import synth_state_dict as _synth_state_dict
     alph = [5000.0, 0.0, 0.0, 0.1, 0.05, 0.02]
     torch.manual_seed(2)
     prob, x0, _, _ = na.initProb("singlequad", 37, 8, 0.3, alph, lambda t: t.float().to(DEV))

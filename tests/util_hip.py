@@ -59,3 +59,21 @@ def full_states(g, seed):
 def count_off(got, want, rtol, atol):
     got, want = got.double().cpu(), torch.as_tensor(want).double()
     return int(((got - want).abs() > atol + rtol * want.abs()).sum()), float((got - want).abs().max())
+
+
+def synth_state_dict(nTh, m, d, seed):
+    """closed-form weights (no RNG): entries s*sin(a i + b j + phase), s ~ 1/sqrt(fan_in)"""
+    def fill(rows, cols, a, b, ph, s):
+        i = torch.arange(rows, dtype=torch.float64).unsqueeze(1)
+        j = torch.arange(cols, dtype=torch.float64).unsqueeze(0)
+        return (s * torch.sin(a * i + b * j + ph)).float()
+    r = min(10, d + 1)
+    sd = {"A": fill(r, d + 1, 0.37, 0.11, 0.1 + seed, 1.0 / (d + 1) ** 0.5),
+          "c.weight": fill(1, d + 1, 0.0, 0.23, 0.4 + seed, 0.3), "c.bias": torch.tensor([0.05]),
+          "w.weight": 1.0 + fill(1, m, 0.0, 0.31, 0.7 + seed, 0.2),
+          "N.layers.0.weight": fill(m, d + 1, 0.41, 0.13, 0.2 + seed, 1.0 / (d + 1) ** 0.5),
+          "N.layers.0.bias": fill(1, m, 0.0, 0.19, 0.3 + seed, 0.1).reshape(m)}
+    for l in range(1, nTh):
+        sd[f"N.layers.{l}.weight"] = fill(m, m, 0.29 + 0.01 * l, 0.17, 0.5 + seed + l, 1.0 / m ** 0.5)
+        sd[f"N.layers.{l}.bias"] = fill(1, m, 0.0, 0.27, 0.6 + seed + l, 0.1).reshape(m)
+    return sd

@@ -126,6 +126,7 @@ def main(argv=None):
         Jc.backward()
         optim.step()
         torch.cuda.synchronize()
+        na.check_errors()                                 # (after the synchronisation: a timed-out rollout raises instead of training on NaN)
         dt = time.time() - end
         total += dt
         line = "{:05d} {:7.1e} {:6.2f}   {:9.3e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}".format(
