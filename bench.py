@@ -184,6 +184,53 @@ def bench_shock(args, dev):
     print(json.dumps(out), flush=True)
 
 
+def quick_measure(name, dev, steps=10, warmup=3):
+    """one of the other BASELINE.json configurations at its full size, a few calls (the headline stays swarm50): what the driver's line
+    carries in config.other_workloads"""
+    L = _lib.lib()
+    if name == "singlequad-shock":
+        from neuraloc_amd.shock import shock_sweep
+        meta, sd, xtarget, xInit = load_workload("singlequad")
+        net, prob = build_objects(meta, sd, xtarget, dev)
+        n, nt = meta["n_full"], meta["nt"]
+        x = make_states(meta, xInit, n, seed=200).to(dev)
+        times = [0.1 * k for k in range(1, 10)]
+        shocks = torch.zeros(1, meta["d"], device=dev)
+        shocks[0, 0:3] = torch.tensor([0.5, -0.5, 0.25])
+        for _ in range(2):
+            shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / reps
+        return {"workload": f"singlequad-shock n={n} x {len(times)} shock times nt={nt} (trajectories and controls kept)",
+                "traj_per_s": len(times) * n / el, "ms_per_sweep": 1e3 * el, "kernel": L.nocf_last_rollout_kernel().decode()}
+    meta, sd, xtarget, xInit = load_workload(name)
+    net, prob = build_objects(meta, sd, xtarget, dev)
+    n, nt = meta["n_full"], meta["nt"]
+    x = make_states(meta, xInit, n, seed=200).to(dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", meta["alph"])
+        torch.cuda.synchronize()
+        L.nocf_profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", meta["alph"])
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        kms, nl = C.c_double(0.0), C.c_int32(0)
+        L.nocf_profile_end(C.byref(kms), C.byref(nl))
+    kernel_ms = kms.value / max(1, nl.value)
+    achieved = flops_per_state_step(meta) * n * nt / (kernel_ms * 1e-3) / 1e12
+    return {"workload": f"{name} d={meta['d']} m={meta['m']} nt={nt} n={n}", "traj_per_s": n / el, "ms_per_step": 1e3 * el,
+            "kernel": L.nocf_last_rollout_kernel().decode(), "kernel_ms": kernel_ms,
+            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of": "fp32 MFMA / vector peak 157.3 TFLOP/s (the small networks are latency-bound VALU work: SURVEY 8d)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +242,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="batch rows: the GLOBAL batch (strong) or rows per GPU (weak); default: BASELINE.json's n")
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of the other four BASELINE configs and the shock sweep")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,6 +309,7 @@ def main():
         elapsed = time.perf_counter() - t0
         kms, nl = C.c_double(0.0), C.c_int32(0)
         L.nocf_profile_end(C.byref(kms), C.byref(nl))
+    na.check_errors(sync=True)                         # a rollout whose workgroups timed out on each other raises here (its numbers are NaN)
     if dist:
         host_reduce = os.environ.get("NOCF_BENCH_BACKEND", "nccl") != "nccl"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_reduce else dev)
@@ -294,6 +343,14 @@ def main():
                          "hbm_peak_GBps": PEAK_HBM_GBS,
                          "note": "per launch on rank 0: its rows x nt state-steps x SURVEY 8(d) FLOPs, over the kernel's HIP-event time"},
         }
+        if world == 1 and args.workload == "swarm50" and not args.n and not args.nt and not args.no_other_workloads:
+            others = []
+            for name in ("swap2", "softcorridor", "swap12", "singlequad", "singlequad-shock"):
+                try:
+                    others.append(quick_measure(name, dev))
+                except Exception as ex:                          # the headline line must survive a failure here
+                    others.append({"workload": name, "error": repr(ex)[:200]})
+            out["config"]["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(meta, sd, xtarget, x_cpu, nt)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
