@@ -11,10 +11,11 @@
  *   - functions enqueue work on `stream` (a hipStream_t passed as void*, 0 = default
  *     stream) and return without synchronising; nothing is allocated or freed
  *   - return value: 0 ok; <0 argument error (NOCF_E_*); >0 a hipError_t
- *   - no exceptions, no aborts.  Process-global state: the diagnostic environment knobs (NOCF_LANE, NOCF_FIXED,
- *     NOCF_SLAB, NOCF_GROUP, NOCF_DEBUG ...) are read with getenv at each call (the tests toggle kernels with them); the measurement hooks nocf_profile_begin/_end and nocf_debug_set_* keep a list of HIP
- *     events / a diagnostic buffer pointer and are NOT thread-safe.  The compute entry points themselves
- *     keep no state between calls (the caller owns the workspace)
+ *   - no exceptions, no aborts.  Process-global state: the diagnostic environment knobs (NOCF_LANE, NOCF_FIXED, NOCF_DUO,
+ *     NOCF_MONO, NOCF_DEBUG ...) are read from the environment once, at first use, and cached (nocf_debug_reload_env drops the
+ *     cache); the measurement hooks nocf_profile_begin/_end, nocf_last_rollout_kernel, nocf_last_rollout_status_async and
+ *     nocf_debug_set_* keep a list of HIP events / the last launch's name and error-word address / a diagnostic buffer pointer
+ *     and are NOT thread-safe.  The compute entry points themselves keep no state between calls (the caller owns the workspace)
  */
 #ifndef NOCF_H
 #define NOCF_H
@@ -102,6 +103,10 @@ const char* nocf_last_rollout_kernel(void);
  * *host_word != 0 means the rollout failed (0x3000 + the exchange kind that timed out).  Returns 1 when a copy was enqueued, 0 when
  * the last rollout kernel has no such word (*host_word is set to 0), or an error code.  The Python layer raises RuntimeError from it. */
 int nocf_last_rollout_status_async(uint32_t* host_word, void* stream);
+
+/* The library reads its NOCF_* environment knobs once (first use) and caches them; this drops the cache so that the next call reads
+ * the environment again (tests that switch kernels between calls; the Python layer calls it when NOCF_ENV_WATCH=1). */
+void nocf_debug_reload_env(void);
 
 /* bytes of scratch `workspace` a call with these shapes needs (packed weight images) */
 size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh);

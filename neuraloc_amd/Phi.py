@@ -94,13 +94,18 @@ class Phi(nn.Module):
         st.cw = dv(self.c.weight, "c.weight")
         st.cb = 0.0
         st.cb_dev = dv(self.c.bias, "c.bias")           # read on the device: no device-to-host copy (a sync) per call
-        # (one workspace per module, repacked by every call: calls on the same Phi must be on one stream)
+        # One workspace per module AND STREAM (every call repacks it and the kernels scribble in it while they run): calls on the
+        # same Phi from two streams each get their own and cannot race.
         nbytes = _lib.lib().nocf_rollout_workspace_bytes(self.d, self.m, self.nTh, int(n))
         if nbytes == 0:
             raise RuntimeError("nocf_workspace_bytes: unsupported (d, m, nTh)")
-        if self._ws is None or self._ws.device != dev or self._ws.numel() < nbytes:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        return st, keep, self._ws
+        if self._ws is None:
+            self._ws = {}
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return st, keep, ws
 
     def _c_struct64(self):
         """(NocfPhi64, keep-alive list, workspace) for a double-precision rollout: the module after .to(torch.float64)"""
@@ -131,9 +136,13 @@ class Phi(nn.Module):
         nbytes = _lib.lib().nocf_workspace_bytes_f64(self.d, self.m, self.nTh)
         if nbytes == 0:
             raise RuntimeError("nocf_workspace_bytes_f64: unsupported (d, m, nTh)")
-        ws = getattr(self, "_ws64", None)
-        if ws is None or ws.device != dev or ws.numel() < nbytes:
-            ws = self._ws64 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        pool = getattr(self, "_ws64", None)
+        if pool is None:
+            pool = self._ws64 = {}
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)        # (per stream: see _c_struct)
+        ws = pool.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = pool[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         return st, keep, ws
 
     def _phi64(self, x, value):

@@ -51,6 +51,7 @@ def lib():
     """the loaded library; raises RuntimeError when it was not built (python __graft_entry__.py)"""
     global _lib
     if _lib is not None:
+        watch_env(_lib)
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"neuraloc_amd: HIP library {LIB_PATH} is missing. Build it with "
@@ -77,6 +78,7 @@ def lib_for(d, m, nTh, r, n_agents):
         return lib()
     L = _jit_libs.get(key)
     if L is not None:
+        watch_env(L)
         return L
     import subprocess
     import sys
@@ -157,6 +159,7 @@ def _bind(L):
     L.nocf_prob_eval_f64.argtypes = [C.POINTER(NocfProb64), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.nocf_phi_f64.restype = C.c_int
     L.nocf_phi_f64.argtypes = [C.POINTER(NocfPhi64), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.nocf_debug_reload_env.restype = None
     L.nocf_last_rollout_status_async.restype = C.c_int
     L.nocf_last_rollout_status_async.argtypes = [C.c_void_p, C.c_void_p]
     L.nocf_debug_set_stamp_buffer.restype = C.c_int
@@ -172,6 +175,20 @@ def _bind(L):
 # when the status has already arrived.  A failed rollout's outputs are NaN in any case.
 _pending = []          # [event, pinned host word, description]
 _free_words = []
+
+
+_env_sig = None
+
+
+def watch_env(L):
+    """NOCF_ENV_WATCH=1 (tests): the library caches its NOCF_* knobs; drop the cache when one of them has changed since the last call"""
+    global _env_sig
+    if os.environ.get("NOCF_ENV_WATCH", "0") in ("", "0"):
+        return
+    sig = (id(L),) + tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("NOCF_")))
+    if sig != _env_sig:
+        _env_sig = sig
+        L.nocf_debug_reload_env()
 
 
 def track_rollout_status(L, device, what):

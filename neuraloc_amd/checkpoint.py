@@ -16,14 +16,17 @@ def load_file(path, trusted=False):
     tensors; that one class is allow-listed for the weights-only unpickler, so loading a checkpoint cannot run code.
     trusted=True (or NOCF_TRUST_CHECKPOINTS=1) falls back to the full unpickler for files that hold other objects."""
     import os
+    import pickle
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as exc:                              # noqa: BLE001 -- unpickling errors come in many types
+    except pickle.UnpicklingError as exc:
+        # only the "unsupported global" refusal of the weights-only unpickler lands here: a missing or unreadable file (OSError),
+        # a truncated archive (RuntimeError / EOFError) ... propagate as they are and never reach the full unpickler
         if trusted or os.environ.get("NOCF_TRUST_CHECKPOINTS", "0") not in ("", "0"):
             return torch.load(path, map_location="cpu", weights_only=False)
-        raise RuntimeError(f"{path}: not loadable with the weights-only unpickler ({exc}); if you trust the file, pass "
-                           "trusted=True or set NOCF_TRUST_CHECKPOINTS=1") from exc
+        raise RuntimeError(f"{path}: the weights-only unpickler refused an object in this file ({exc}); if you trust the file -- the full "
+                           "unpickler can run code -- pass trusted=True or set NOCF_TRUST_CHECKPOINTS=1") from exc
 
 
 def load_checkpoint(path, device="cuda:0", n_train=None, n_val=None, var0=None, dtype=torch.float32):

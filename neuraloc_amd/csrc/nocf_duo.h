@@ -18,3 +18,6 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra, float*
                const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1);
 
 long duo_rows_per_launch(void);
+
+// NOCF_* knob, read from the environment once and cached (nocf_kernels.hip); nocf_debug_reload_env() drops the cache
+int nocf_env_int(const char* name, int dflt);

@@ -407,7 +407,9 @@ __host__ __device__ inline long duo_x_layout(int NT, DXOff* o) {
 
 struct DuoRun { long row0, n_total; };             // rows of this launch inside the caller's batch (chunked launches; sAll indexing)
 
-template <int PD, bool REC>
+// REC: the training variant also stores every stage input (RollArgs::sAll); ZF: intermediates (trajectories and controls, one more
+// evaluation per step); the plain evaluation variant carries no trace of either
+template <int PD, bool REC, bool ZF>
 __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __restrict__ dpp, DevProb pb, float* ws, RollArgs ra, DuoRun rr) {
     const DuoPlan& dp = *dpp;
     const int bid = blockIdx.x;
@@ -591,7 +593,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 
         // the owner's step, state part: gradient of evaluation e-1 -> RK update -> stage state of evaluation e published.
         // Leaves this lane's share of sum p^2 (q0) and its candidate for dPhi/dt (gdv) for the cost part.
-        auto own_state = [&](int s, int e, float hs, int pst, float t_pub, bool have, u32x4 (&pv)[DU_G], float& q0, float& gdv, unsigned& qa, unsigned& qb) {
+        auto own_state = [&](int s, int e, float hs, int pst, int pk, float t_pub, bool have, u32x4 (&pv)[DU_G], float& q0, float& gdv, unsigned& qa, unsigned& qb) {
             const int t = s >> 1, j = s & 1;
             const int parG = (e - 1) & 1, parS = e & 1;
             const bool rk_last = (pst == nstage - 1);
@@ -601,7 +603,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             DTL(40 * t + 0);
             const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2];      // (in flight while the partials are polled)
             if (!have) g_request(s, parG, pv);
-            {   // the cost scalars of this sample ride along (consumed by own_costs, behind P1): their round trip is off the critical path
+            if (pst != nstage) {   // the cost scalars of this sample ride along (consumed by own_costs, behind P1): their round trip is off the critical path
                 const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((parG * NT + t) * DU_G + member) * 4 + 2 * j) * 4, 16);
                 qa = v2[0]; qb = v2[1];
             }
@@ -611,6 +613,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) if (pact && pi + e4 < d) q0 += gs[e4] * gs[e4];
             gdv = pd_e == 0 ? gs[0] : (pd_e == 1 ? gs[1] : (pd_e == 2 ? gs[2] : gs[3]));
+            const bool pctrl = (pst == nstage);                   // the evaluation just answered was a control evaluation (intermediates)
+            const long orow = rr.row0 + own_row(t, j);            // this sample's row in the caller's batch
+            const bool orow_ok = own_row(t, j) < ra.n;
             if (pact) {
                 const float z0[4] = {z04.x, z04.y, z04.z, z04.w};
                 float zA[4] = {zA4.x, zA4.y, zA4.z, zA4.w}, zn[4];
@@ -621,16 +626,29 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     const float K = hs * -gs[e4];                          // dx = -grad_p H = -p (src/OCflow.py:134, :143-184)
                     float x_;
                     zn[e4] = z0[e4];
-                    if (rk_last) { x_ = (nstage == 1 ? z0[e4] : zA[e4]) + rk_wa * K; zn[e4] = x_; }
+                    if (pctrl) x_ = z0[e4];                                // controls only: the state stands, the next step starts from it
+                    else if (rk_last) { x_ = (nstage == 1 ? z0[e4] : zA[e4]) + rk_wa * K; zn[e4] = x_; }
                     else { zA[e4] = (pst == 0 ? z0[e4] : zA[e4]) + rk_wa * K; x_ = z0[e4] + rk_wx * K; }
                     xs[e4] = (i < d) ? x_ : (i == d ? t_pub : 0.f);
                     if (i >= d) { zn[e4] = 0.f; zA[e4] = 0.f; }
                 }
+                if (ZF && orow_ok) {
+                    // intermediates (src/OCflow.py:37-55), time-major: the state at the end of step pk; the controls -p at (z_{k+1}, t_k)
+                    if (pctrl) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 < d) ra.ctrlFull[((long)(pk + 1) * rr.n_total + orow) * ra.cdim + pi + e4] = -gs[e4];
+                    } else if (rk_last) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 < d) ra.zFull[((long)(pk + 1) * rr.n_total + orow) * (d + 4) + pi + e4] = zn[e4];
+                    }
+                }
                 const int lp = (psl * 16 + 2 * member + j) * 16 + pmt * 1024;
                 du_st(g, lp, xS + ((parS * NT + t) * DU_KBD) * 1024, xs);
                 du_st_sent(g, lp, xS + (((parS ^ 1) * NT + t) * DU_KBD) * 1024);
-                if (rk_last) L4[(sbase + DS_Z0 + pi) >> 2] = make_float4(zn[0], zn[1], zn[2], zn[3]);
-                else L4[(sbase + DS_ZA + pi) >> 2] = make_float4(zA[0], zA[1], zA[2], zA[3]);
+                if (!pctrl) {
+                    if (rk_last) L4[(sbase + DS_Z0 + pi) >> 2] = make_float4(zn[0], zn[1], zn[2], zn[3]);
+                    else L4[(sbase + DS_ZA + pi) >> 2] = make_float4(zA[0], zA[1], zA[2], zA[3]);
+                }
                 L4[(sbase + DS_XS + pi) >> 2] = make_float4(xs[0], xs[1], xs[2], xs[3]);
                 // training: the stage input of evaluation e (index e-1); the terminal evaluation is not recorded
                 if (REC && ra.sAll && e <= ra.nt * nstage && own_row(t, j) < ra.n) {
@@ -643,7 +661,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         };
         // ... cost part (off the critical path: it runs behind P1, while the u0 exchange travels): sum p^2, dPhi/dt, the x-only terms
         // from role B -> the four cost integrals of evaluation e-1
-        auto own_costs = [&](int s, int e, float hs, int pst, float q0, float gdv, bool have, unsigned qa, unsigned qb) {
+        auto own_costs = [&](int s, int e, float hs, int pst, int pk, float q0, float gdv, bool have, unsigned qa, unsigned qb) {
             const int t = s >> 1, j = s & 1;
             const int parG = (e - 1) & 1;
             const bool rk_last = (pst == nstage - 1);
@@ -675,8 +693,11 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const float K = hs * val;
                 float* cz = lds + sbase + DS_CZ + lane;                     // [0..3] value, [4..7] RK accumulator
                 const float cz0 = cz[0], czA = cz[4];
-                if (rk_last) cz[0] = (nstage == 1 ? cz0 : czA) + rk_wa * K;
-                else cz[4] = (pst == 0 ? cz0 : czA) + rk_wa * K;
+                if (rk_last) {
+                    const float cn = (nstage == 1 ? cz0 : czA) + rk_wa * K;
+                    cz[0] = cn;
+                    if (ZF && own_row(t, j) < ra.n) ra.zFull[((long)(pk + 1) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 4) + d + lane] = cn;
+                } else cz[4] = (pst == 0 ? cz0 : czA) + rk_wa * K;
             }
             DTL(40 * t + 3);
         };
@@ -739,11 +760,16 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             }
             if (REC && ra.sAll && own_row(t, j) < ra.n)
                 for (int i = lane; i <= d; i += 64) ra.sAll[(rr.row0 + own_row(t, j)) * (d + 1) + i] = lds[sbase + DS_XS + i];
+            if (ZF && own_row(t, j) < ra.n) {                 // z_0 = [x, 0, 0, 0, 0]; the controls of slot 0 stay zero (SURVEY 8a note 3)
+                for (int i = lane; i < d + 4; i += 64) ra.zFull[(rr.row0 + own_row(t, j)) * (d + 4) + i] = (i < d) ? lds[sbase + DS_Z0 + i] : 0.f;
+                for (int i = lane; i < ra.cdim; i += 64) ra.ctrlFull[(rr.row0 + own_row(t, j)) * ra.cdim + i] = 0.f;
+            }
         }
 
         double tk = ra.t0;
         int e = 0;
-        float p_hs = 0.f; int p_st = 0;
+        float p_hs = 0.f; int p_st = 0, p_k = 0;
+        const int nsub = nstage + (ZF ? 1 : 0);             // evaluations per step: the RK stages (+ the control evaluation of intermediates)
         u32x4 pf[DU_G];                                            // prefetched partial gradients of own sample pf_s (-1: none)
         unsigned pf_qa = 0, pf_qb = 0;
         int pf_s = -1;
@@ -751,13 +777,14 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             const bool fin = (k == ra.nt);
             const double t1k = tk + ra.h;
             const double hsd = t1k - tk;                           // stepRK4 re-derives h = t1 - t0 (src/OCflow.py:170)
-            for (int st = 0; st < (fin ? 1 : nstage); ++st) {
+            for (int st = 0; st < (fin ? 1 : nsub); ++st) {
                 ++e;
                 const int par = e & 1;
                 DTL_EPOCH(e);
                 // time of this evaluation: stepRK4's t0, t0 + h/2, t0 + h/2, t0 + h in double (src/OCflow.py:157-184); the terminal
-                // evaluation runs at tspan[1] (src/OCflow.py:62)
-                const double te = fin ? ra.t1 : ((nstage == 1 || st == 0) ? tk : (st == 3 ? tk + hsd : tk + hsd / 2));
+                // evaluation runs at tspan[1] (src/OCflow.py:62); the control evaluation of intermediates at the step's START time with the
+                // step's END state (src/OCflow.py:51-55: tk is advanced behind it)
+                const double te = fin ? ra.t1 : ((nstage == 1 || st == 0 || st == nstage) ? tk : (st == 3 ? tk + hsd : tk + hsd / 2));
                 // tile after tile: while this workgroup multiplies tile t, role B works on the tile before it
                 for (int t = 0; t < NT; ++t) {
                     const int s0 = 2 * t, s1 = 2 * t + 1;
@@ -765,7 +792,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     float cq0 = 0.f, cgd = 0.f;
                     const bool pf_have = DU_PREFETCH_G && pf_s == sown && sown >= 0;                 // the partials were requested in front of the previous P2
                     unsigned qa_ = 0, qb_ = 0;
-                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, (float)te, pf_have, pf, cq0, cgd, qa_, qb_);
+                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, pf_have, pf, cq0, cgd, qa_, qb_);
                     pf_s = -1;
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
@@ -795,7 +822,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // (in the shadow of the u0 exchange) the cost integrals of the previous evaluation; z = A s, A^T z + c of the own sample
                     // (the owner of a sample integrates its costs; the wave two places on -- it owns nothing of this tile -- does the z work)
                     if (sown >= 0) {
-                        if (e > 1) own_costs(sown, e, p_hs, p_st, cq0, cgd, true, qa_, qb_);
+                        if (e > 1 && p_st != nstage) own_costs(sown, e, p_hs, p_st, p_k, cq0, cgd, true, qa_, qb_);
                     } else {
                         azc_step((s0 & 3) == (wave ^ 2) ? s0 : s1, fin);
                     }
@@ -861,7 +888,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         }
                     }
                 }
-                p_hs = (float)hsd; p_st = st;
+                p_hs = (float)hsd; p_st = st; p_k = k;
                 if (fin) break;
             }
             tk += ra.h;
@@ -915,16 +942,18 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         if (tid < 64) lds[DB_VEC + tid] = ws[dp.oVec + 2 * 64 * DU_G + member * 64 + tid];
         __syncthreads();
         const DXPar xp = du_x_params(pb, PD);
-        const int E = ra.nt * nstage + 1;
+        const int nsub = nstage + (ZF ? 1 : 0);
+        const int E = ra.nt * nsub + 1;
         u32x4 spf = {0u, 0u, 0u, 0u};                              // prefetched own-state piece of tile spf_t (-1: none)
         int spf_t = -1;
         for (int e = 1; e <= E; ++e) {
             const bool fin = (e == E);
+            const bool stage = !fin && ((e - 1) % nsub) < nstage;         // an RK stage: its running costs are integrated (not: terminal, control)
             const int par = e & 1;
             DTL_EPOCH(e);
             for (int t = 0; t < NT; ++t) {
                 DTL(40 * t + 20);
-                if (!fin) {
+                if (stage) {
                     // ================= x-only cost terms of the own samples of tile t at the state of evaluation e =================
                     if (wave < 2) {                                     // 80 pieces of 16 B: dims 4 l .. 4 l + 3 of own sample j
                         const int p = tid < 80 ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, mt = r_ >> 2, sl = r_ & 3;
@@ -1019,7 +1048,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 // a store is not answered before the store is: vmcnt retires in order), consumed at the next tile's entry
                 if (wave < 2 && !fin) {
                     const int tn = (t + 1 < NT) ? t + 1 : 0, pn = (t + 1 < NT) ? par : (par ^ 1);
-                    if (!(t + 1 >= NT && e + 1 == E)) {
+                    const int en = (t + 1 < NT) ? e : e + 1;
+                    if (en < E && ((en - 1) % nsub) < nstage) {
                         const int p = tid < 80 ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, mt = r_ >> 2, sl = r_ & 3;
                         spf = du_ld(g, xS + ((pn * NT + tn) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16, 0);
                         spf_t = tn;
@@ -1063,10 +1093,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int du_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
+static int du_env_int(const char* name, int dflt) { return nocf_env_int(name, dflt); }      // (cached: nocf_kernels.hip)
 
 long duo_rows_per_launch(void) { return 32L * 16 * DU_NTMAX; }
 
@@ -1113,19 +1140,21 @@ int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size
     return 0;
 }
 
-template <int PD, bool REC>
-static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC>); }
+template <int PD, bool REC, bool ZF>
+static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF>); }
 
 int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, float* ws, size_t ws_bytes, hipStream_t st,
                const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
-    if (pb.kind == NOCF_PROB_QUADCOPTER || ra_in.zFull) return 1;
+    if (pb.kind == NOCF_PROB_QUADCOPTER || (ra_in.zFull && ra_in.sAll)) return 1;
     const long chunk = duo_rows_per_launch();
     DuoPlan dp0;
     if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(ra_in.n, chunk), &dp0) != 0) return 1;
     if (ws_bytes < duo_ws_bytes_of(dp0)) return 1;
     const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
     const bool rec = ra_in.sAll != nullptr;
-    const void* fk = c2 ? (rec ? duo_fn<2, true>() : duo_fn<2, false>()) : (rec ? duo_fn<3, true>() : duo_fn<3, false>());
+    const bool zf = ra_in.zFull != nullptr;
+    const void* fk = c2 ? (rec ? duo_fn<2, true, false>() : (zf ? duo_fn<2, false, true>() : duo_fn<2, false, false>()))
+                        : (rec ? duo_fn<3, true, false>() : (zf ? duo_fn<3, false, true>() : duo_fn<3, false, false>()));
     // residency: all 16 x ngroups workgroups spin on each other, so every one of them must be resident at once: two per CU
     // (256 registers per lane, <= 80 KB LDS).  The grid is checked against what the runtime says fits; the stream must be
     // otherwise idle (a concurrent kernel on another stream can take the CUs: the bounded polls then time out and the host raises).

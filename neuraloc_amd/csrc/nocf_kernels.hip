@@ -1501,10 +1501,23 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 // ------------------------------------------------------------------------------------------
 // host side: plan construction and the C ABI
 // ------------------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
+// The NOCF_* knobs are read from the environment ONCE (first use) and cached: a launch does no getenv.  Tests that change a knob between
+// calls invalidate the cache with nocf_debug_reload_env() (neuraloc_amd/_lib.py does it when NOCF_ENV_WATCH=1, which tests/conftest.py sets).
+#include <map>
+#include <mutex>
+#include <string>
+static std::mutex g_env_mu;
+static std::map<std::string, int> g_env_cache;
+int nocf_env_int(const char* name, int dflt) {
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    auto it = g_env_cache.find(name);
+    if (it != g_env_cache.end()) return it->second == INT32_MIN ? dflt : it->second;
     const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
+    const int val = (v && *v) ? atoi(v) : INT32_MIN;
+    g_env_cache[name] = val;
+    return val == INT32_MIN ? dflt : val;
 }
+static int env_int(const char* name, int dflt) { return nocf_env_int(name, dflt); }
 
 // host wrapper: geometry knobs from the environment, then the (constexpr) layout
 static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, int bwd = 0) {
@@ -1636,6 +1649,11 @@ extern "C" {
 int nocf_version(void) { return NOCF_VERSION; }
 
 const char* nocf_last_rollout_kernel(void) { return g_last_kernel; }
+
+void nocf_debug_reload_env(void) {
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    g_env_cache.clear();
+}
 
 int nocf_last_rollout_status_async(uint32_t* host_word, void* stream) {
     if (!host_word) return NOCF_E_NULL;

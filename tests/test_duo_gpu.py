@@ -252,3 +252,58 @@ def test_duo_training_step_matches_the_tile_kernel(monkeypatch):
         res[duo] = (float(Jc.detach()), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu())
     assert abs(res["1"][0] - res["0"][0]) <= 2e-5 * abs(res["0"][0])
     assert (res["1"][1] - res["0"][1]).abs().max().item() <= 1e-2 * res["0"][1].abs().max().item()
+
+
+@pytest.mark.parametrize("tag", ["eval_rk4", "eval_seg", "train_rk4", "eval_rk1"])
+def test_duo_intermediates_against_reference_golden(tag, monkeypatch):
+    """intermediates=True on the split-role kernel (one more evaluation per step: the controls at (z_{k+1}, t_k)): the reference's stored
+    trajectories and controls, incl. slot 0 of the controls (zero) and the off-by-one control time (src/OCflow.py:51-55)"""
+    g = load_golden("swarm50")
+    if not g.has(tag + "/zFull"):
+        pytest.skip("no such entry")
+    monkeypatch.setenv("NOCF_DUO", "1")
+    net = make_net(g, DEV)
+    prob = make_prob(g, DEV, training=tag.startswith("train"))
+    tspan = [float(v) for v in g[tag + "/tspan"]]
+    nt = int(g[tag + "/nt"])
+    stepper = "rk1" if tag.endswith("rk1") else "rk4"
+    zw = torch.from_numpy(g[tag + "/zFull"])
+    cw = torch.from_numpy(g[tag + "/ctrlFull"])
+    x = g.t("x")[:zw.shape[0]].to(DEV)
+    with torch.no_grad():
+        zF, cF = na.OCflow(x, net, prob, tspan, nt, stepper, g.meta["alph"], intermediates=True)
+    assert _kernel() == "rollout_duo_kernel"
+    assert zF.shape == zw.shape and cF.shape == cw.shape
+    bad, worst = count_off(zF.cpu(), zw, 1e-5, 1e-4)
+    assert bad <= zw.numel() // 2000, f"{tag}: {bad} trajectory entries off (worst {worst:g})"
+    bad, worst = count_off(cF.cpu(), cw, 1e-4, 1e-4 * float(cw.abs().max()) + 1e-5)
+    assert bad <= cw.numel() // 2000, f"{tag}: {bad} control entries off (worst {worst:g})"
+    assert float(cF[:, :, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n", [5, 600, 2100])
+def test_duo_intermediates_match_the_tile_kernel(n, monkeypatch):
+    g = load_golden("swarm50")
+    m = g.meta
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
+    x = (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 7)).contiguous().to(DEV)
+    out = {}
+    for duo in ("1", "0"):
+        monkeypatch.setenv("NOCF_DUO", duo)
+        with torch.no_grad():
+            zF, cF = na.OCflow(x, net, prob, [0.0, 1.0], 8, "rk4", m["alph"], intermediates=True)
+        assert (_kernel() == "rollout_duo_kernel") == (duo == "1")
+        out[duo] = (zF.cpu(), cF.cpu())
+    na.check_errors(sync=True)
+    # at 8 steps some of these trajectories are unstable (a rounding difference grows 5x per step: 1e-5 after one step, 0.25 at the end, between
+    # two correct fp32 kernels), so the first half of the time slices is compared tightly and the rest by count
+    d = m["d"]
+    (zd, cd), (zt, ct) = out["1"], out["0"]
+    assert torch.equal(zd[:, :, 0], zt[:, :, 0]) and float(cd[:, :, 0].abs().max()) == 0.0
+    assert (zd[:, :d, :5] - zt[:, :d, :5]).abs().max().item() <= 2e-3
+    assert (cd[:, :, :5] - ct[:, :, :5]).abs().max().item() <= 2e-2 * ct.abs().max().item()
+    drift = (zd[:, :d, :] - zt[:, :d, :]).abs().amax(dim=(1, 2))
+    assert int((drift > 1e-2).sum()) <= 2 + n // 20, f"{int((drift > 1e-2).sum())} trajectories drift apart"
+    calm = drift <= 1e-3                                               # on the calm trajectories the running cost L (column d) agrees too
+    rel = (zd[calm, d, :] - zt[calm, d, :]).abs() / (1.0 + zt[calm, d, :].abs())
+    assert float(rel.max()) <= 2e-3

@@ -9,6 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 os.environ.setdefault("NOCF_LIB_PATH", os.path.join(REPO, "neuraloc_amd", "csrc", "libnocf_stamps.so"))
 
+os.environ["NOCF_ENV_WATCH"] = "1"
 import torch                                   # noqa: E402
 import bench                                   # noqa: E402
 import neuraloc_amd as na                      # noqa: E402

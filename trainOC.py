@@ -2,9 +2,9 @@
 """trainOC-style driver on the MI355X path.
 
 Same flags, log columns and checkpoint layout as the reference driver (trainOC.py:22-63 flags, :155-160 header,
-:176-196 iteration line, :199-207 checkpoint, :249-265 lr decay / resampling / alph switch -- with ONE deliberate difference: at every lr decay the parameters really roll
-back to the best validated ones (the reference's reload is a no-op because its bestParams aliases the live tensors; --lr_reload alias
-reproduces that)); every OCflow call --
+:176-196 iteration line, :199-207 checkpoint, :249-265 lr decay / resampling / alph switch, including the reference's behaviour at an lr
+decay: its "reload of the best parameters" is a no-op because bestParams aliases the live tensors, and so it is here by default
+(--lr_reload clone really rolls back, and then also resets Adam's moments)); every OCflow call --
 forward, Jc.backward(), validation -- runs in the HIP kernels.  No plotting (viz_freq is accepted and ignored).
 
 One GPU:   python trainOC.py --data softcorridor --niters 200
@@ -40,7 +40,7 @@ _FLAGS = [
     ("gpu", int, 0, "device index of a single-process run"),
     ("prec", str, "single", "the HIP path is fp32"),
     ("approach", str, "ocflow", ""),
-    ("lr_reload", str, "clone", "(addition) clone: every lr_freq roll back to the best validated parameters; alias: the reference's no-op"),
+    ("lr_reload", str, "alias", "(addition) alias: the reference's behaviour (its reload at lr_freq is a no-op); clone: really roll back to the best validated parameters and reset Adam's moments"),
     ("viz_freq", int, 100, "ignored: nothing is plotted"),
     ("val_freq", int, 25, "validate every this many iterations"),
     ("log_freq", int, 1, "print every this many iterations"),
@@ -149,11 +149,12 @@ def main(argv=None):
         if itr % args.log_freq == 0:
             say(line)
         if itr % args.lr_freq == 0 and best_params is not None:
-            # DELIBERATE DEVIATION (default): roll back to the best parameters so far.  In the reference, bestParams =
-            # net.state_dict() ALIASES the live tensors (trainOC.py:199), so its load_state_dict(bestParams) at lr_freq
-            # (:250-253) is a no-op; --lr_reload alias reproduces that for like-for-like convergence comparisons.
+            # In the reference, bestParams = net.state_dict() ALIASES the live tensors (trainOC.py:199), so its
+            # load_state_dict(bestParams) at lr_freq (:250-253) is a no-op: the default here too (--lr_reload alias).  --lr_reload clone
+            # rolls back to the best validated parameters for real; Adam's moments belong to the abandoned iterates and are reset.
             if args.lr_reload == "clone":
                 net.load_state_dict(best_params)
+                optim.state.clear()
             for g in optim.param_groups:
                 g["lr"] *= args.lr_decay
         if itr % args.sample_freq == 0:
