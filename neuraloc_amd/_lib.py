@@ -66,40 +66,123 @@ _BUILTIN_SHAPES = {(150, 512, 2, 10, 50), (12, 128, 2, 10, 1), (40, 32, 2, 10, 2
                    (4, 16, 2, 5, 2), (4, 32, 2, 5, 2), (24, 32, 2, 10, 12), (8, 32, 2, 9, 4), (12, 32, 2, 10, 6),
                    (16, 32, 2, 10, 8), (20, 32, 2, 10, 10)}
 _jit_libs = {}
+_jit_started = set()
+
+
+def _jit_mode():
+    """NOCF_JIT: "0" never; "1" compile the shape's library NOW (blocking, about a minute) and use it; "auto" (default) use a cached
+    per-shape library when there is one, otherwise start its compilation in a child process, keep the generic instantiation for THIS
+    process (one process never changes kernels for a shape mid-run) and let the next process find the cache."""
+    v = os.environ.get("NOCF_JIT", "auto").strip().lower()
+    return "0" if v in ("", "0", "off", "no") else ("1" if v in ("1", "on", "yes") else "auto")
+
+
+def _jit_paths(key):
+    csrc = os.path.dirname(os.path.abspath(LIB_PATH))
+    out_dir = os.path.join(csrc, "jit")
+    so = os.path.join(out_dir, "libnocf_d%d_m%d_t%d_r%d_a%d.so" % key)
+    src = os.path.join(csrc, "nocf_kernels.hip")
+    inc = os.path.join(os.path.dirname(os.path.dirname(csrc)), "include")
+    deps = [src, os.path.join(inc, "nocf.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".inc") or f.endswith(".h")]
+    return csrc, out_dir, so, src, inc, deps
+
+
+def _jit_cmd(key, out):
+    import shutil
+    csrc, _, _, src, inc, _ = _jit_paths(key)
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        return None
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNOCF_JIT_ONLY",
+            "-DNOCF_XS_D=%d" % key[0], "-DNOCF_XS_M=%d" % key[1], "-DNOCF_XS_T=%d" % key[2], "-DNOCF_XS_R=%d" % key[3],
+            "-DNOCF_XS_A=%d" % key[4], "-I" + inc, "-I" + csrc, "-o", out, src]
+
+
+def _jit_fresh(key):
+    """path of the cached per-shape library if it exists and is newer than every source it was built from"""
+    _, _, so, _, _, deps = _jit_paths(key)
+    try:
+        return so if os.path.getmtime(so) >= max(os.path.getmtime(f) for f in deps) else None
+    except OSError:
+        return None
+
+
+def _jit_start_background(key):
+    """one compilation at a time per cache directory (lock file), detached child, atomic rename on success; never raises"""
+    import subprocess
+    import sys
+    import time
+    if key in _jit_started:
+        return False
+    _jit_started.add(key)
+    try:
+        _, out_dir, so, _, _, _ = _jit_paths(key)
+        os.makedirs(out_dir, exist_ok=True)
+        lock = os.path.join(out_dir, ".compiling")
+        try:
+            if time.time() - os.path.getmtime(lock) > 1800:
+                os.unlink(lock)                                   # a compilation that died
+        except OSError:
+            pass
+        tmp = "%s.%d.tmp" % (so, os.getpid())
+        cmd = _jit_cmd(key, tmp)
+        if cmd is None:
+            return False
+        try:                                                      # a compilation of these sources that failed (its log is kept): not again
+            _, _, _, _, _, deps = _jit_paths(key)
+            if not os.path.exists(so) and os.path.getmtime(so + ".log") >= max(os.path.getmtime(f) for f in deps):
+                return False
+        except OSError:
+            pass
+        try:
+            fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+            os.close(fd)
+        except OSError:
+            return False                                          # somebody (another rank, another shape) is compiling: next time
+        import shlex
+        sh = "%s > %s 2>&1 && mv -f %s %s; rm -f %s %s" % (" ".join(shlex.quote(c) for c in cmd), shlex.quote(so + ".log"),
+                                                           shlex.quote(tmp), shlex.quote(so), shlex.quote(tmp), shlex.quote(lock))
+        subprocess.Popen(["/bin/sh", "-c", sh], stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                         start_new_session=True)
+        print("[neuraloc_amd] shape d=%d m=%d nTh=%d r=%d agents=%d has no specialised kernels in the shipped library: compiling them in the "
+              "background (about a minute, cached under csrc/jit/; this process keeps the generic instantiation, NOCF_JIT=1 waits for "
+              "the compiler instead, NOCF_JIT=0 switches this off)" % key, file=sys.stderr, flush=True)
+        return True
+    except Exception:                                             # noqa: BLE001 -- an optimisation must never take the rollout down
+        return False
 
 
 def lib_for(d, m, nTh, r, n_agents):
-    """The library to run a rollout of this shape with.  Normally the shipped one (its generic kernel instantiation takes
-    any shape).  With NOCF_JIT=1 a shape it does not specialise gets its own library: the same source compiled by hipcc
-    with -DNOCF_XS_* (the plan as a compile-time constant: 1.3-1.8x on the tile kernels), once, cached under
-    csrc/jit/.  Same C ABI, same entry points."""
+    """The library to run a rollout of this shape with.  The shipped one specialises the shapes of the reference's checkpoints and
+    initProb defaults (_BUILTIN_SHAPES) and takes any other shape with its generic instantiation; such a shape gets its own library --
+    the same source compiled by hipcc with -DNOCF_XS_* (the plan as a compile-time constant: 1.3-1.8x on the tile kernels, no
+    scratch), cached under csrc/jit/ -- automatically: see _jit_mode.  Same C ABI, same entry points."""
     key = (int(d), int(m), int(nTh), int(r), int(n_agents))
-    if os.environ.get("NOCF_JIT", "0") in ("", "0") or key in _BUILTIN_SHAPES or "NOCF_LIB_PATH" in os.environ:
+    mode = _jit_mode()
+    if mode == "0" or key in _BUILTIN_SHAPES or "NOCF_LIB_PATH" in os.environ:
         return lib()
     L = _jit_libs.get(key)
     if L is not None:
         watch_env(L)
         return L
-    import subprocess
-    import sys
-    csrc = os.path.dirname(os.path.abspath(LIB_PATH))
-    out_dir = os.path.join(csrc, "jit")
-    os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libnocf_d%d_m%d_t%d_r%d_a%d.so" % key)
-    src = os.path.join(csrc, "nocf_kernels.hip")
-    deps = [src, os.path.join(os.path.dirname(os.path.dirname(csrc)), "include", "nocf.h")] + \
-           [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".inc")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    so = _jit_fresh(key)
+    if so is None and mode == "1":
+        import subprocess
+        import sys
+        _, out_dir, so, _, _, _ = _jit_paths(key)
+        os.makedirs(out_dir, exist_ok=True)
         tmp = "%s.%d.tmp" % (so, os.getpid())
-        inc = os.path.join(os.path.dirname(os.path.dirname(csrc)), "include")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNOCF_JIT_ONLY",
-               "-DNOCF_XS_D=%d" % key[0], "-DNOCF_XS_M=%d" % key[1], "-DNOCF_XS_T=%d" % key[2], "-DNOCF_XS_R=%d" % key[3],
-               "-DNOCF_XS_A=%d" % key[4], "-I" + inc, "-I" + csrc, "-o", tmp, src]
+        cmd = _jit_cmd(key, tmp)
+        if cmd is None:
+            raise RuntimeError("NOCF_JIT=1 but hipcc was not found (set HIPCC)")
         print("[neuraloc_amd] NOCF_JIT=1: specialising the kernels for shape d=%d m=%d nTh=%d r=%d agents=%d (about a minute, once)" % key,
               file=sys.stderr, flush=True)
         subprocess.check_call(cmd)
         os.replace(tmp, so)                       # atomic: ranks that compile the same shape at once do not clash
+    if so is None:                                # auto, nothing cached yet
+        _jit_start_background(key)
+        L = _jit_libs[key] = lib()
+        return L
     L = _jit_libs[key] = _bind(C.CDLL(so))
     return L
 

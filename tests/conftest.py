@@ -11,6 +11,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 # the library caches its NOCF_* knobs; the tests switch kernels with them between calls: the Python layer then drops the cache on a change
 os.environ["NOCF_ENV_WATCH"] = "1"
+# unlisted shapes: no background compilations from the test-suite (the JIT tests switch it on themselves)
+os.environ.setdefault("NOCF_JIT", "0")
 
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 PRETRAINED = ["swap2", "softcorridor", "swap12", "swarm50", "singlequad"]

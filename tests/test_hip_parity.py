@@ -646,6 +646,60 @@ def test_jit_specialisation_of_an_unlisted_shape(monkeypatch, capfd):
     assert (a[2] - b[2]).abs().max().item() <= 2e-6 * b[2].abs().max().item()
 
 
+def test_jit_auto_mode_compiles_in_the_background_and_the_next_process_uses_the_cache(tmp_path):
+    """NOCF_JIT=auto (the default outside this test-suite): the first process that meets an unlisted shape keeps the generic
+    instantiation and starts hipcc in a child process; a later process loads the cached per-shape library and takes the
+    specialised kernels; both agree"""
+    import shutil
+    import subprocess
+    import sys
+    import time
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this box")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    key = (8, 40, 2, 9, 4)
+    so = os.path.join(repo, "neuraloc_amd", "csrc", "jit", "libnocf_d%d_m%d_t%d_r%d_a%d.so" % key)
+    for f in (so, so + ".log"):
+        if os.path.exists(f):
+            os.unlink(f)
+    child = r"""
+import os, sys
+sys.path.insert(0, os.environ["NOCF_REPO"]); sys.path.insert(0, os.path.join(os.environ["NOCF_REPO"], "tests"))
+import torch
+import neuraloc_amd as na
+from util_hip import synth_state_dict
+dev = torch.device("cuda:0")
+alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+torch.manual_seed(9)
+prob, x0, _, _ = na.initProb("midcross4", 16, 16, 0.5, alph, lambda t: t.float().to(dev))
+net = na.Phi(nTh=2, m=40, d=x0.shape[1], alph=alph)
+net.load_state_dict(synth_state_dict(2, 40, x0.shape[1], seed=4))
+net = net.to(dev); prob.eval()
+with torch.no_grad():
+    a = na.OCflow(x0, net, prob, [0.0, 1.0], 6, "rk4", alph, noMean=True)[1]
+    b = na.OCflow(x0, net, prob, [0.0, 1.0], 6, "rk4", alph, noMean=True)[1]
+torch.cuda.synchronize()
+assert all(torch.equal(u, v) for u, v in zip(a, b))          # one process, one kernel: run-to-run identical
+print("TABLE", " ".join("%.9e" % float(c.double().sum()) for c in a))
+"""
+    env = dict(os.environ)
+    env.update({"NOCF_JIT": "auto", "NOCF_DEBUG": "1", "NOCF_MONO": "0", "NOCF_REPO": repo})
+    env.pop("NOCF_LIB_PATH", None)
+    r1 = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    assert "compiling them in the background" in r1.stderr and "shape-specialised" not in r1.stderr
+    t0 = time.time()
+    while not os.path.exists(so) and time.time() - t0 < 420:
+        time.sleep(2.0)
+    assert os.path.exists(so), "the background compilation did not deliver: " + (open(so + ".log").read()[-2000:] if os.path.exists(so + ".log") else "no log")
+    r2 = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert "shape-specialised" in r2.stderr and "compiling them in the background" not in r2.stderr
+    t1 = [float(v) for v in [ln for ln in r1.stdout.splitlines() if ln.startswith("TABLE")][-1].split()[1:]]
+    t2 = [float(v) for v in [ln for ln in r2.stdout.splitlines() if ln.startswith("TABLE")][-1].split()[1:]]
+    assert all(abs(a - b) <= 2e-6 * max(1.0, abs(b)) for a, b in zip(t1, t2))
+
+
 @pytest.mark.parametrize("name", ["swap2", "softcorridor", "swap12"])
 def test_lane_adjoint_agrees_with_tile_adjoint(name, monkeypatch, capfd):
     """small networks: the one-wave-per-sample adjoint (gradient rows in registers) and the 4-samples-per-wave tile

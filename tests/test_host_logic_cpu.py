@@ -34,3 +34,94 @@ def test_single_process_reductions_are_identities():
     s = torch.arange(8.0)
     assert torch.equal(reduce_cost_sums(s.clone()), s)
     assert shard_rows(10, 0, 1) == (0, 10)
+
+
+# ---- per-shape JIT: which library a shape gets (neuraloc_amd/_lib.py lib_for); no GPU, no compute calls
+
+def _fake_hipcc(tmp_path, ok=True, delay=0.0):
+    """a stand-in compiler: copies the shipped library to the -o path (or fails), so the cache logic runs without hipcc's minute"""
+    import stat
+    from neuraloc_amd import _lib
+    sh = tmp_path / "fake_hipcc.sh"
+    body = "#!/bin/sh\nout=\nwhile [ $# -gt 0 ]; do if [ \"$1\" = -o ]; then out=$2; fi; shift; done\nsleep %g\n" % delay
+    body += ("cp %s \"$out\"\n" % _lib.LIB_PATH) if ok else "echo 'error: no' >&2; exit 1\n"
+    sh.write_text(body)
+    sh.chmod(sh.stat().st_mode | stat.S_IEXEC)
+    return str(sh)
+
+
+def _wait_for(path, seconds=20.0):
+    import os
+    import time
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        if os.path.exists(path):
+            return True
+        time.sleep(0.05)
+    return False
+
+
+def test_jit_modes_and_the_background_cache(tmp_path, monkeypatch):
+    import os
+    import shutil
+    from neuraloc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import pytest
+        pytest.skip("library not built")
+    # a private copy of the library directory: the cache (csrc/jit/) of the real tree stays untouched
+    csrc = tmp_path / "pkg" / "csrc"                            # <root>/<package>/csrc next to <root>/include, like the repo
+    shutil.copytree(os.path.dirname(_lib.LIB_PATH), csrc, ignore=shutil.ignore_patterns("jit", "obj", "*stamps*"))
+    os.makedirs(tmp_path / "include", exist_ok=True)
+    shutil.copy(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(_lib.LIB_PATH))), "include", "nocf.h"), tmp_path / "include" / "nocf.h")
+    monkeypatch.setattr(_lib, "LIB_PATH", str(csrc / "libnocf.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_jit_libs", {})
+    monkeypatch.setattr(_lib, "_jit_started", set())
+    monkeypatch.delenv("NOCF_LIB_PATH", raising=False)
+    key = (8, 48, 2, 9, 4)
+    so = _lib._jit_paths(key)[2]
+    for v, want in (("0", "0"), ("", "0"), ("1", "1"), ("auto", "auto"), ("AUTO", "auto"), ("whatever", "auto")):
+        monkeypatch.setenv("NOCF_JIT", v)
+        assert _lib._jit_mode() == want
+    monkeypatch.delenv("NOCF_JIT")
+    assert _lib._jit_mode() == "auto"
+    # off: the shipped library, nothing started
+    monkeypatch.setenv("NOCF_JIT", "0")
+    assert _lib.lib_for(*key) is _lib.lib() and not os.path.exists(os.path.dirname(so))
+    # built-in shapes never compile
+    monkeypatch.setenv("NOCF_JIT", "auto")
+    monkeypatch.setenv("HIPCC", _fake_hipcc(tmp_path, ok=True, delay=0.3))
+    assert _lib.lib_for(150, 512, 2, 10, 50) is _lib.lib() and not os.path.exists(os.path.dirname(so))
+    # auto, nothing cached: generic now (and for the rest of the process), compilation in the background, one at a time
+    first = _lib.lib_for(*key)
+    assert first is _lib.lib()
+    other = (8, 64, 2, 9, 4)
+    assert _lib.lib_for(*other) is _lib.lib()                   # the lock is held: this one is not started
+    assert _wait_for(so) and _wait_for(so + ".log")
+    assert not _wait_for(_lib._jit_paths(other)[2], 0.5)
+    assert _lib.lib_for(*key) is first                           # the same process keeps its choice
+    # "the next process": a fresh decision table finds the cache
+    monkeypatch.setattr(_lib, "_jit_libs", {})
+    monkeypatch.setattr(_lib, "_jit_started", set())
+    import time
+    t0 = time.time()
+    while os.path.exists(os.path.join(os.path.dirname(so), ".compiling")) and time.time() - t0 < 10:
+        time.sleep(0.05)
+    got = _lib.lib_for(*key)
+    assert got is not _lib.lib() and got.nocf_version() == _lib.lib().nocf_version()
+    # a failing compiler: log kept, no retry for the same sources, the rollout is never taken down
+    monkeypatch.setenv("HIPCC", _fake_hipcc(tmp_path, ok=False))
+    bad = (8, 80, 2, 9, 4)
+    assert _lib.lib_for(*bad) is _lib.lib()
+    assert _wait_for(_lib._jit_paths(bad)[2] + ".log") and not os.path.exists(_lib._jit_paths(bad)[2])
+    t0 = time.time()
+    while os.path.exists(os.path.join(os.path.dirname(so), ".compiling")) and time.time() - t0 < 10:
+        time.sleep(0.05)
+    monkeypatch.setattr(_lib, "_jit_libs", {})
+    monkeypatch.setattr(_lib, "_jit_started", set())
+    assert _lib._jit_start_background(bad) is False
+    # no compiler at all: generic, silently
+    monkeypatch.setenv("HIPCC", str(tmp_path / "does_not_exist"))
+    monkeypatch.setattr(_lib, "_jit_libs", {})
+    monkeypatch.setattr(_lib, "_jit_started", set())
+    assert _lib.lib_for(8, 96, 2, 9, 4) is _lib.lib()
