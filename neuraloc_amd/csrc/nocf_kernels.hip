@@ -2163,8 +2163,11 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob, const double*
     ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull;
     ra.cdim = nocf_ctrl_dim(&p32, phi->d);
     const size_t ldsBytes = (size_t)pl.ldsDoubles * 8;
-    const void* fk = T == 4 ? reinterpret_cast<const void*>(rollout_f64_kernel<4>)
-                   : T == 2 ? reinterpret_cast<const void*>(rollout_f64_kernel<2>) : reinterpret_cast<const void*>(rollout_f64_kernel<1>);
+    const bool wide = phi->m > 256;
+    const void* fk = wide ? (T == 4 ? reinterpret_cast<const void*>(rollout_f64_kernel<4, true>)
+                             : T == 2 ? reinterpret_cast<const void*>(rollout_f64_kernel<2, true>) : reinterpret_cast<const void*>(rollout_f64_kernel<1, true>))
+                          : (T == 4 ? reinterpret_cast<const void*>(rollout_f64_kernel<4, false>)
+                             : T == 2 ? reinterpret_cast<const void*>(rollout_f64_kernel<2, false>) : reinterpret_cast<const void*>(rollout_f64_kernel<1, false>));
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e) return (int)e;
     if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] f64 kernel: %d sample(s) per workgroup, LDS %zu B\n", T, ldsBytes);
@@ -2194,8 +2197,11 @@ int nocf_phi_f64(const NocfPhi64* phi, const double* s, int64_t n, double* value
     F64Phi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev, phi->d, phi->m, phi->nTh, phi->r};
     hipLaunchKernelGGL(f64_pack_kernel, dim3(512), dim3(256), 0, st, pl, P, ws);
     const size_t ldsBytes = (size_t)pl.ldsDoubles * 8;
-    const void* fk = T == 4 ? reinterpret_cast<const void*>(phi_f64_kernel<4>)
-                   : T == 2 ? reinterpret_cast<const void*>(phi_f64_kernel<2>) : reinterpret_cast<const void*>(phi_f64_kernel<1>);
+    const bool wide = phi->m > 256;
+    const void* fk = wide ? (T == 4 ? reinterpret_cast<const void*>(phi_f64_kernel<4, true>)
+                             : T == 2 ? reinterpret_cast<const void*>(phi_f64_kernel<2, true>) : reinterpret_cast<const void*>(phi_f64_kernel<1, true>))
+                          : (T == 4 ? reinterpret_cast<const void*>(phi_f64_kernel<4, false>)
+                             : T == 2 ? reinterpret_cast<const void*>(phi_f64_kernel<2, false>) : reinterpret_cast<const void*>(phi_f64_kernel<1, false>));
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e) return (int)e;
     const double* wsc = ws;
