@@ -1477,12 +1477,31 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
     for (; r < r1; ++r) a[0] += X[r * n + col];
     part[(long)blockIdx.x * n + col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
+// 32 columns x 8 slabs of the partials per workgroup (one thread walking all ~1000 partials of a column was a 0.3 ms dependent chain,
+// four times per training iteration); fixed order: 4 interleaved chains per slab, the slabs summed pairwise through LDS
 __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out, int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= n) return;
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, gsl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(long)b * n + col];
-    out[col] = accumulate ? out[col] + s : s;
+    if (col < n) {
+        const int per = (nblocks + 7) / 8;
+        const int b0 = gsl * per, b1 = (b0 + per < nblocks) ? b0 + per : nblocks;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += part[(long)(b + u) * n + col];
+        }
+        for (; b < b1; ++b) a[0] += part[(long)b * n + col];
+        s = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    sh[gsl][cl] = s;
+    __syncthreads();
+    if (gsl == 0 && col < n) {
+        const float t = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) + ((sh[4][cl] + sh[5][cl]) + (sh[6][cl] + sh[7][cl]));
+        out[col] = accumulate ? out[col] + t : t;
+    }
 }
 
 __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* __restrict__ b, int K, float* __restrict__ out) {
@@ -1747,7 +1766,7 @@ int nocf_colsum_f32(const float* X, int64_t K, int32_t n, float* out, int32_t ac
     nblocks = (K + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((int)nblocks, cb), dim3(256), 0, st, X, (long)K, n, rpb, scratch);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cb), dim3(256), 0, st, scratch, (int)nblocks, n, out, accumulate);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, scratch, (int)nblocks, n, out, accumulate);
     return (int)hipGetLastError();
 }
 

@@ -32,10 +32,18 @@ def _contract(X, Y, out=None):
     """X' Y for row streams X [K, m], Y [K, n] (out += when given).  Small and medium outputs (up to about 128 x 128:
     everything but the 512-wide swarm50 network) go to the library's two-launch contraction -- a library GEMM with such
     an output and 10^5..10^6 rows runs on a handful of workgroups (0.4-1.4 ms each); wide ones are library GEMMs
-    (hipBLASLt, near its fp32 peak for 512x512 outputs)."""
+    (hipBLASLt), split over the rows."""
     m, n = X.shape[1], Y.shape[1]
     if m > 512 or n > 512 or m * n > 128 * 160:
-        r = X.t() @ Y
+        # a 512 x 512 (x 151) output is 64 (24) tiles of the library's GEMM: a quarter of the chip.  Split the 10^5..10^6 rows into S
+        # slabs, one batched GEMM, fixed-order sum of the S partial products (swarm50: 2.15 -> 1.19 ms and 0.94 -> 0.45 ms per product,
+        # tools/gemm_splitk_probe.py)
+        K = X.shape[0]
+        S = next((s for s in (16, 8, 4, 2) if K % s == 0 and K // s >= 8192), 1)
+        if S > 1 and X.is_contiguous() and Y.is_contiguous():
+            r = torch.bmm(X.view(S, K // S, m).transpose(1, 2), Y.view(S, K // S, n)).sum(0)
+        else:
+            r = X.t() @ Y
         return r if out is None else out.add_(r)
     dev = X.device
     sc = _SCRATCH.get(dev)
