@@ -72,6 +72,7 @@ enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P =
 #define DS_ZQ 640                                  // [16]  z = A s
 #define DS_CZ 656                                  // [8]   cost integrals L, HJt, Q, W: value, RK accumulator
 #define DS_PHX 664                                 // [2]   c.s and 1/2 |A s|^2 (final time)
+#define DS_OC 668                                  // [4]   the owner's step -> its cost part: sum p^2, dPhi/dt, the x-only terms q, w
 #define DS_STRIDE 672
 // Role B: P4's A-operand image, w slice, the staged v tile, the y fragments (also: the positions of the cost pass), cost partials
 #define DB_K4 0                                    // [10 mt][4 kb][64][4]
@@ -274,8 +275,12 @@ __device__ __forceinline__ void du_gather2(DCtx& g, int which, int lane, int sby
 // acc = sum over NKB k-blocks of W[kb] (A operand: AccVGPRs if ACC, else VGPRs) x the staged fragments at LDS float4 index b4 + kb*64 (B operand).
 // Two accumulation chains (a dependent v_mfma_f32_16x16x4_f32 may issue 40 cycles behind its producer; the chains alternate
 // at 32), B fragments read 3 k-blocks (12 MFMAs = 384 cycles) ahead of their use.
-template <int NKB, bool ACC>
-__device__ __forceinline__ f32x4 du_gemm_lds(const f32x4 (&W)[NKB], int b4) {
+struct DuNoMid { __device__ __forceinline__ void operator()(int) const {} };
+// mid(kb): called behind every k-block's MFMAs (kb is a compile-time constant after unrolling) -- stores / loads that only have to be
+// ISSUED before the product ends (slot resets behind the second k-block, the epilogue's LDS operands two k-blocks before the end) go
+// there: they issue in the shadow of the MFMAs instead of in front of the first one or behind the last
+template <int NKB, bool ACC, typename Mid = DuNoMid>
+__device__ __forceinline__ f32x4 du_gemm_lds(const f32x4 (&W)[NKB], int b4, Mid mid = Mid()) {
     const float4* L4 = reinterpret_cast<const float4*>(lds);
     float4 ring[4];
 #pragma unroll
@@ -294,6 +299,7 @@ __device__ __forceinline__ f32x4 du_gemm_lds(const f32x4 (&W)[NKB], int b4) {
             else { mfma_v(a0, W[kb][0], b.x); mfma_v(a1, W[kb][1], b.y); }
             mfma_v(a0, W[kb][2], b.z); mfma_v(a1, W[kb][3], b.w);
         }
+        mid(kb);
     }
     DU_FENCE2(a0, a1);
     return a0 + a1;
@@ -593,7 +599,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 
         // the owner's step, state part: gradient of evaluation e-1 -> RK update -> stage state of evaluation e published.
         // Leaves this lane's share of sum p^2 (q0) and its candidate for dPhi/dt (gdv) for the cost part.
-        auto own_state = [&](int s, int e, float hs, int pst, int pk, float t_pub, bool have, u32x4 (&pv)[DU_G], float& q0, float& gdv, unsigned& qa, unsigned& qb) {
+        auto own_state = [&](int s, int e, float hs, int pst, int pk, float t_pub, bool have, u32x4 (&pv)[DU_G]) {
             const int t = s >> 1, j = s & 1;
             const int parG = (e - 1) & 1, parS = e & 1;
             const bool rk_last = (pst == nstage - 1);
@@ -603,16 +609,17 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             DTL(40 * t + 0);
             const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2];      // (in flight while the partials are polled)
             if (!have) g_request(s, parG, pv);
-            if (pst != nstage) {   // the cost scalars of this sample ride along (consumed by own_costs, behind P1): their round trip is off the critical path
+            unsigned qa = 0, qb = 0;
+            if (pst != nstage) {   // the cost scalars of this sample ride along (consumed by own_costs, behind P2): their round trip is off the critical path
                 const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((parG * NT + t) * DU_G + member) * 4 + 2 * j) * 4, 16);
                 qa = v2[0]; qb = v2[1];
             }
             const f32x4 gs = gather_g(s, parG, true, pv);
             DTL(40 * t + 1);
-            q0 = 0.f;
+            float q0 = 0.f;
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) if (pact && pi + e4 < d) q0 += gs[e4] * gs[e4];
-            gdv = pd_e == 0 ? gs[0] : (pd_e == 1 ? gs[1] : (pd_e == 2 ? gs[2] : gs[3]));
+            const float gdv = pd_e == 0 ? gs[0] : (pd_e == 1 ? gs[1] : (pd_e == 2 ? gs[2] : gs[3]));
             const bool pctrl = (pst == nstage);                   // the evaluation just answered was a control evaluation (intermediates)
             const long orow = rr.row0 + own_row(t, j);            // this sample's row in the caller's batch
             const bool orow_ok = own_row(t, j) < ra.n;
@@ -620,15 +627,20 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const float z0[4] = {z04.x, z04.y, z04.z, z04.w};
                 float zA[4] = {zA4.x, zA4.y, zA4.z, zA4.w}, zn[4];
                 f32x4 xs;
+                // straight-line form of the three cases (selects on wave-uniform conditions, the same operations as the branches:
+                //   controls only:  x = z0 (the state stands);   last stage:  x = z_{k+1} = (z0 | zA) + wa K;   else:  zA += wa K, x = z0 + wx K)
+                const bool xFromA = !pctrl && rk_last && nstage != 1;      // x starts from the accumulator
+                const bool accum = !pctrl && !rk_last;                     // the accumulator takes this stage
+                const float cx = pctrl ? 0.f : (rk_last ? rk_wa : rk_wx);
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int i = pi + e4;
                     const float K = hs * -gs[e4];                          // dx = -grad_p H = -p (src/OCflow.py:134, :143-184)
-                    float x_;
-                    zn[e4] = z0[e4];
-                    if (pctrl) x_ = z0[e4];                                // controls only: the state stands, the next step starts from it
-                    else if (rk_last) { x_ = (nstage == 1 ? z0[e4] : zA[e4]) + rk_wa * K; zn[e4] = x_; }
-                    else { zA[e4] = (pst == 0 ? z0[e4] : zA[e4]) + rk_wa * K; x_ = z0[e4] + rk_wx * K; }
+                    const float xb = xFromA ? zA[e4] : z0[e4];
+                    const float x_ = pctrl ? z0[e4] : xb + cx * K;
+                    const float an = (pst == 0 ? z0[e4] : zA[e4]) + rk_wa * K;
+                    zA[e4] = accum ? an : zA[e4];
+                    zn[e4] = (rk_last && !pctrl) ? x_ : z0[e4];
                     xs[e4] = (i < d) ? x_ : (i == d ? t_pub : 0.f);
                     if (i >= d) { zn[e4] = 0.f; zA[e4] = 0.f; }
                 }
@@ -658,17 +670,25 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 }
             }
             DTL(40 * t + 2);
+            // (behind the store: off the critical path) what the cost part needs, parked in LDS -- P1 and P2 run between the two
+            if (pst != nstage) {
+                const float sp2 = sum64(q0);
+                const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gdv), pd_lane));
+                if (lane == 0) L4[(sbase + DS_OC) >> 2] = make_float4(sp2, gt, __uint_as_float(qa), __uint_as_float(qb));
+            }
         };
         // ... cost part (off the critical path: it runs behind P1, while the u0 exchange travels): sum p^2, dPhi/dt, the x-only terms
         // from role B -> the four cost integrals of evaluation e-1
-        auto own_costs = [&](int s, int e, float hs, int pst, int pk, float q0, float gdv, bool have, unsigned qa, unsigned qb) {
+        auto own_costs = [&](int s, int e, float hs, int pst, int pk) {
             const int t = s >> 1, j = s & 1;
             const int parG = (e - 1) & 1;
             const bool rk_last = (pst == nstage - 1);
             const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
             const int sbase = DA_T + s * DS_STRIDE;
-            const float sp2 = sum64(q0);
-            const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gdv), pd_lane));
+            const float4 oc = L4[(sbase + DS_OC) >> 2];
+            const float sp2 = oc.x, gt = oc.y;
+            unsigned qa = __float_as_uint(oc.z), qb = __float_as_uint(oc.w);
+            bool have = true;
             // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
             float q_ = 0.f, w_ = 0.f;
             {
@@ -789,10 +809,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 for (int t = 0; t < NT; ++t) {
                     const int s0 = 2 * t, s1 = 2 * t + 1;
                     const int sown = ((s0 & 3) == wave) ? s0 : (((s1 & 3) == wave) ? s1 : -1);      // this wave's own sample of the tile, if any
-                    float cq0 = 0.f, cgd = 0.f;
                     const bool pf_have = DU_PREFETCH_G && pf_s == sown && sown >= 0;                 // the partials were requested in front of the previous P2
-                    unsigned qa_ = 0, qb_ = 0;
-                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, pf_have, pf, cq0, cgd, qa_, qb_);
+                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, pf_have, pf);
                     pf_s = -1;
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
@@ -804,9 +822,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     __syncthreads();
                     DTL(40 * t + 5);
                     {
-                        const f32x4 acc = du_gemm_lds<DU_KBD, false>(K0r, (DA_SF >> 2) + lane);
+                        float4 b0s;                                                // bias of this lane's 4 features 16 wave + 4 slot + e
+                        const f32x4 acc = du_gemm_lds<DU_KBD, false>(K0r, (DA_SF >> 2) + lane, [&](int kb) { if (kb == DU_KBD - 3) b0s = L4[(DA_VEC >> 2) + 4 * wave + slot]; });
                         DTL(40 * t + 6);
-                        const float4 b0s = L4[(DA_VEC >> 2) + 4 * wave + slot];    // bias of this lane's 4 features 16 wave + 4 slot + e
                         const float b0v[4] = {b0s.x, b0s.y, b0s.z, b0s.w};
                         f32x4 sg, th;
 #pragma unroll
@@ -819,13 +837,6 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 #ifdef NOCF_STAMPS
                     if (dp.dbg & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DTL(40 * t + 18); }      // how long do the five stores take to be acknowledged?
 #endif
-                    // (in the shadow of the u0 exchange) the cost integrals of the previous evaluation; z = A s, A^T z + c of the own sample
-                    // (the owner of a sample integrates its costs; the wave two places on -- it owns nothing of this tile -- does the z work)
-                    if (sown >= 0) {
-                        if (e > 1 && p_st != nstage) own_costs(sown, e, p_hs, p_st, p_k, cq0, cgd, true, qa_, qb_);
-                    } else {
-                        azc_step((s0 & 3) == (wave ^ 2) ? s0 : s1, fin);
-                    }
                     DTL(40 * t + 8);
                     // With several tiles per group the partial gradients of the NEXT tile's own sample have usually arrived by now (role B
                     // worked on that tile while this workgroup multiplied this one): request them (and the cost scalars) here, so that their
@@ -850,13 +861,14 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         // epilogue: no load of this wave waits behind them, and the GEMM covers their acknowledgement (V one phase early:
                         // header, H1)
                         const int fr = (((par ^ 1) * NT + t) * DU_KBM + 4 * member + wave) * 1024;
-                        du_st_sent(g, vb, xU + fr);
-                        du_st_sent(g, vb, xT + fr);
-                        du_st_sent(g, vb, xV + fr);
-                        const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DA_UF >> 2) + lane);
+                        float4 b1s, wvs;
+                        auto resets = [&](int kb) {
+                            if (kb == 1) { du_st_sent(g, vb, xU + fr); du_st_sent(g, vb, xT + fr); du_st_sent(g, vb, xV + fr); }
+                            if (kb == DU_KBM - 3) { b1s = L4[((DA_VEC + 64) >> 2) + 4 * wave + slot]; wvs = L4[((DA_VEC + 128) >> 2) + 4 * wave + slot]; }
+                        };
+                        const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DA_UF >> 2) + lane, resets);
                         DTL(40 * t + 11);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the resets are acknowledged -- long ago -- before V is stored: header, H1)
-                        const float4 b1s = L4[((DA_VEC + 64) >> 2) + 4 * wave + slot], wvs = L4[((DA_VEC + 128) >> 2) + 4 * wave + slot];
                         const float b1v[4] = {b1s.x, b1s.y, b1s.z, b1s.w}, wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
                         f32x4 v;
 #ifdef NOCF_STAMPS
@@ -887,6 +899,15 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                             }
                         }
                     }
+                    // (behind P2, while v travels and role B multiplies) the owner of a sample integrates its costs of the previous evaluation
+                    // and forms z = A s, A^T z + c for its NEXT step -- wave-local: no other wave reads what it writes.  (In front of the U
+                    // gather these two delayed it: they take as long as the u0 hop.  The waves that own nothing of this tile go on: with two
+                    // tiles they are the next tile's owners.)
+                    if (sown >= 0) {
+                        if (e > 1 && p_st != nstage) own_costs(sown, e, p_hs, p_st, p_k);
+                        azc_step(sown, fin);
+                    }
+                    DTL(40 * t + 9);
                 }
                 p_hs = (float)hsd; p_st = st; p_k = k;
                 if (fin) break;
@@ -1005,10 +1026,17 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
                 DTL(40 * t + 24);
                 du_gather<DU_KBM>(g, wave, lane, xV + ((par * NT + t) * DU_KBM) * 1024, DB_VF >> 2, DUK_V);
-                {
+                __syncthreads();
+                DTL(40 * t + 25);
+                u32x4 thv = {DU_SENT, DU_SENT, DU_SENT, DU_SENT};
+                float4 wvs;
+                auto mid = [&](int kb) {
+                    if (kb == DU_KBM - 3) wvs = L4[(DB_VEC >> 2) + 4 * wave + slot];
+                    if (kb != 1) return;
                     // V(e) is complete, so every owner has read the partial gradients and the cost scalars of the previous evaluation
-                    // (it published S(e) after them): reset those slots now.  The tanh(o) load below is younger than these stores, and
-                    // vmcnt retires in order: its wait lies between the resets and the payloads stored at the end of P4 (header, H1).
+                    // (it published S(e) after them): reset those slots now (behind the second k-block: the stores issue in the MFMAs'
+                    // shadow).  The tanh(o) load is younger than these stores, and vmcnt retires in order: its wait lies between the resets
+                    // and the payloads stored at the end of P4 (header, H1).
                     const int gR = xG + ((((par ^ 1) * NT + t) * DU_G + member) * DU_KBD) * 1024;
 #pragma unroll
                     for (int mi = 0; mi < 3; ++mi) { const int mt = wave + 4 * mi; if (mt < DU_KBD) du_st_sent(g, vb, gR + mt * 1024); }
@@ -1019,11 +1047,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 16);
                     }
-                }
-                u32x4 thv = du_ld(g, vb, xT + fo);
-                __syncthreads();
-                DTL(40 * t + 25);
-                const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DB_VF >> 2) + lane);
+                    thv = du_ld(g, vb, xT + fo);
+                };
+                const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DB_VF >> 2) + lane, mid);
                 DTL(40 * t + 26);
                 {
                     int spins = 0;
@@ -1035,15 +1061,13 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the resets above have landed: see there)
                 {
                     const f32x4 th = du_f(thv);
-                    const float4 wvs = L4[(DB_VEC >> 2) + 4 * wave + slot];
                     float4 y;
                     y.x = th[0] * (wvs.x + hN * acc[0]); y.y = th[1] * (wvs.y + hN * acc[1]);
                     y.z = th[2] * (wvs.z + hN * acc[2]); y.w = th[3] * (wvs.w + hN * acc[3]);
                     L4[(DB_YF >> 2) + wave * 64 + lane] = y;
                 }
                 DTL(40 * t + 27);
-                __syncthreads();
-                DTL(40 * t + 28);
+                // (in front of the barrier: they do not depend on y, and the other waves' epilogues cover them)
                 // the own-state pieces of the NEXT tile's cost pass: requested here, in front of P4 and its stores (a load issued behind
                 // a store is not answered before the store is: vmcnt retires in order), consumed at the next tile's entry
                 if (wave < 2 && !fin) {
@@ -1055,12 +1079,17 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         spf_t = tn;
                     }
                 }
+                float4 wf[2][4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) wf[0][kb] = L4[(DB_K4 >> 2) + (wave * 4 + kb) * 64 + lane];     // P4's first weights
+                __syncthreads();
+                DTL(40 * t + 28);
                 // ================= P4: partial g = K0[H_c,:]^T y for the dim tiles wave, wave+4, wave+8 =================
                 const int gP = xG + (((par * NT + t) * DU_G + member) * DU_KBD) * 1024;
                 {
-                    float4 bf[4], wf[2][4];
+                    float4 bf[4];
 #pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) { bf[kb] = L4[(DB_YF >> 2) + kb * 64 + lane]; wf[0][kb] = L4[(DB_K4 >> 2) + (wave * 4 + kb) * 64 + lane]; }
+                    for (int kb = 0; kb < 4; ++kb) bf[kb] = L4[(DB_YF >> 2) + kb * 64 + lane];
 #pragma unroll
                     for (int mi = 0; mi < 3; ++mi) {
                         const int mt = wave + 4 * mi;
