@@ -17,7 +17,7 @@ from neuraloc_amd import _lib                  # noqa: E402
 
 A_PT = {0: "own: entry", 1: "own: partial gradients valid", 2: "own: RK done, S stored", 3: "own: costs done",
         4: "P1: at the S gather", 5: "P1: S staged (barrier passed)", 6: "P1: gemm done", 7: "P1: epilogue + stores", 18: "P1: stores acknowledged (NOCF_DUO_DBG=4)",
-        8: "z / A^T z done: at the U gather", 10: "P2: U staged (barrier passed)", 11: "P2: gemm done", 16: "P2: bias / w read", 17: "P2: tanh done", 12: "P2: V stored"}
+        8: "at the U gather", 9: "costs, z / A^T z done (owner waves)", 10: "P2: U staged (barrier passed)", 11: "P2: gemm done", 16: "P2: bias / w read", 17: "P2: tanh done", 12: "P2: V stored"}
 B_PT = {20: "tile entry", 21: "own states loaded + barrier", 22: "pair sums + barrier", 23: "QW stored",
         24: "P3: at the V gather", 25: "P3: V staged (barrier passed)", 26: "P3: gemm done", 27: "P3: th valid, y written",
         28: "P3: barrier passed", 29: "P4: done (G stored)"}
