@@ -55,7 +55,6 @@
 #define DU_R 8                     // B fragments in flight per wave (1 KiB each)
 #define DU_NTMAX 4                 // tiles of 16 samples per group (LDS carve of role A)
 #define DU_SENT 0xFFFFFFFFu
-#define DU_PREFETCH_G 0              // 1: request the next owner step's partial gradients in front of P2 (32 more live registers: it spills -- 8.4 vs 5.9 ms; kept for a build with more register room)
 enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P = 7, DUK_XCC = 8 };
 
 // LDS carve (float offsets).  Role A: A, c, the member's slices of b0 / b1 / w, the staged S and U tiles, per-sample owner state.
@@ -409,7 +408,7 @@ __host__ __device__ inline long duo_x_layout(int NT, DXOff* o) {
     long x = 0;
     auto take = [&](long nfl) { const long at = x; x += (nfl + 63) / 64 * 64; return at; };
     const long s = take(2L * NT * DU_KBD * 256), u = take(2L * NT * DU_KBM * 256), t = take(2L * NT * DU_KBM * 256), v = take(2L * NT * DU_KBM * 256);
-    const long gg = take(2L * NT * DU_G * DU_KBD * 256), q = take(2L * NT * DU_G * 4), p = take((long)NT * DU_G * 4 * 16);
+    const long gg = take(2L * NT * DU_G * DU_KBD * 256), q = take(3L * NT * DU_G * 4), p = take((long)NT * DU_G * 4 * 16);
     if (o) { o->S = (int)(s * 4); o->U = (int)(u * 4); o->T = (int)(t * 4); o->V = (int)(v * 4); o->G = (int)(gg * 4); o->Q = (int)(q * 4); o->P = (int)(p * 4); }
     return x;                                      // floats per group
 }
@@ -614,7 +613,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             if (!have) g_request(s, parG, pv);
             unsigned qa = 0, qb = 0;
             if (pst != nstage) {   // the cost scalars of this sample ride along (consumed by own_costs, behind P2): their round trip is off the critical path
-                const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((parG * NT + t) * DU_G + member) * 4 + 2 * j) * 4, 16);
+                const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((e - 1) % 3) * NT + t) * DU_G + member) * 4 + 2 * j) * 4, 16);
                 qa = v2[0]; qb = v2[1];
             }
             const f32x4 gs = gather_g(s, parG, true, pv);
@@ -695,7 +694,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
             float q_ = 0.f, w_ = 0.f;
             {
-                const int ob = xQ + (((parG * NT + t) * DU_G + member) * 4 + 2 * j) * 4;
+                const int ob = xQ + (((((e - 1) % 3) * NT + t) * DU_G + member) * 4 + 2 * j) * 4;
                 int spins = 0;
                 while (true) {
                     if (!have) { const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, ob, 16); qa = v2[0]; qb = v2[1]; }
@@ -793,9 +792,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         int e = 0;
         float p_hs = 0.f; int p_st = 0, p_k = 0;
         const int nsub = nstage + (ZF ? 1 : 0);             // evaluations per step: the RK stages (+ the control evaluation of intermediates)
-        u32x4 pf[DU_G];                                            // prefetched partial gradients of own sample pf_s (-1: none)
-        unsigned pf_qa = 0, pf_qb = 0;
-        int pf_s = -1;
+        u32x4 pf[DU_G];                                            // the 8 members' partial gradients of an own sample (this lane's 16 bytes of each)
         for (int k = 0; k <= ra.nt; ++k) {
             const bool fin = (k == ra.nt);
             const double t1k = tk + ra.h;
@@ -812,9 +809,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 for (int t = 0; t < NT; ++t) {
                     const int s0 = 2 * t, s1 = 2 * t + 1;
                     const int sown = ((s0 & 3) == wave) ? s0 : (((s1 & 3) == wave) ? s1 : -1);      // this wave's own sample of the tile, if any
-                    const bool pf_have = DU_PREFETCH_G && pf_s == sown && sown >= 0;                 // the partials were requested in front of the previous P2
-                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, pf_have, pf);
-                    pf_s = -1;
+                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, false, pf);
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
                     // (the two waves that own nothing of this tile fetch the stage states: the owners have just stored theirs, and a load issued
@@ -841,20 +836,6 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     if (dp.dbg & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DTL(40 * t + 18); }      // how long do the five stores take to be acknowledged?
 #endif
                     DTL(40 * t + 8);
-                    // With several tiles per group the partial gradients of the NEXT tile's own sample have usually arrived by now (role B
-                    // worked on that tile while this workgroup multiplied this one): request them (and the cost scalars) here, so that their
-                    // L2 round trip runs under P2 instead of in front of the next owner's step.
-                    if (DU_PREFETCH_G && NT > 1 && !fin) {
-                        const int tn = (t + 1 < NT) ? t + 1 : 0, en = (t + 1 < NT) ? e : e + 1;
-                        const int n0 = 2 * tn, n1 = 2 * tn + 1;
-                        const int sn = ((n0 & 3) == wave) ? n0 : (((n1 & 3) == wave) ? n1 : -1);
-                        if (sn >= 0 && en > 1) {
-                            pf_s = sn;
-                            g_request(sn, (en - 1) & 1, pf);
-                            const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((en - 1) & 1) * NT + tn) * DU_G + member) * 4 + 2 * (sn & 1)) * 4, 16);
-                            pf_qa = v2[0]; pf_qb = v2[1];
-                        }
-                    }
                     // ================= P2: q = K1[H_c,:] u0 + b1 ; v = tanh(q) . w =================
                     du_gather<DU_KBM>(g, wave, lane, xU + ((par * NT + t) * DU_KBM) * 1024, DA_UF >> 2, DUK_U);
                     __syncthreads();
@@ -1019,7 +1000,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         const float q_ = lds[DB_XP + 2 * lane] + lds[DB_XP + 2 * (lane + 2)], w_ = lds[DB_XP + 2 * lane + 1] + lds[DB_XP + 2 * (lane + 2) + 1];
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 pay = {__float_as_uint(q_), __float_as_uint(w_)};
-                        const int off = xQ + (((par * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;
+                        const int off = xQ + ((((e % 3) * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;       // (three slots: see the reset in P3)
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 16);      // (the slot is reset below, behind the V gather)
                     }
@@ -1036,17 +1017,19 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 auto mid = [&](int kb) {
                     if (kb == DU_KBM - 3) wvs = L4[(DB_VEC >> 2) + 4 * wave + slot];
                     if (kb != 1) return;
-                    // V(e) is complete, so every owner has read the partial gradients and the cost scalars of the previous evaluation
-                    // (it published S(e) after them): reset those slots now (behind the second k-block: the stores issue in the MFMAs'
-                    // shadow).  The tanh(o) load is younger than these stores, and vmcnt retires in order: its wait lies between the resets
-                    // and the payloads stored at the end of P4 (header, H1).
+                    // V(e) is complete, so every owner has read the partial gradients of the previous evaluation (it published S(e) after
+                    // them): reset those slots now (behind the second k-block: the stores issue in the MFMAs' shadow).  The tanh(o) load is
+                    // younger than these stores, and vmcnt retires in order: its wait lies between the resets and the payloads stored at the
+                    // end of P4 (header, H1).  The cost scalars have THREE slots (e mod 3): the owner integrates the costs of evaluation e-1
+                    // behind P2 of evaluation e, i.e. possibly after V(e) is complete, so the slot reset here is the one of evaluation e-2
+                    // (its reader finished before it published S(e)); it next takes the scalars of evaluation e+1.
                     const int gR = xG + ((((par ^ 1) * NT + t) * DU_G + member) * DU_KBD) * 1024;
 #pragma unroll
                     for (int mi = 0; mi < 3; ++mi) { const int mt = wave + 4 * mi; if (mt < DU_KBD) du_st_sent(g, vb, gR + mt * 1024); }
                     if (wave == 0 && lane < 2) {
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 sen = {DU_SENT, DU_SENT};
-                        const int offr = xQ + ((((par ^ 1) * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;
+                        const int offr = xQ + (((((e + 1) % 3) * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 16);
                     }
