@@ -8,40 +8,45 @@
 //     role A (member c):  W2 = K1[H_c,:] resident (128 AccVGPRs)      role B (member c):  W3 = K1[:,H_c]^T resident
 //       own  sum the 8 partial gradients of the own samples, RK update,    xq  obstacle + pair sums of the own samples (x only)
 //            publish the next stage state S                             P3  a[H_c] = w + hN W3 v        (B = V fragments)
-//       P1   o[H_c] = K0[H_c,:] s + b0   (A = LDS image, B = S fragments)    y = tanh(o) . a   (tanh(o) arrives as TH)
+//       P1   o[H_c] = K0[H_c,:] s + b0   (A = 40 VGPRs, B = S fragments)     y = tanh(o) . a   (tanh(o) arrives as TH)
 //            publish u0 = sigma(o) as U, tanh(o) as TH                  P4  partial g = K0[H_c,:]^T y   (A = LDS image)
 //       P2   q[H_c] = W2 u0 + b1         (B = U fragments)                   publish the partial as G
 //            publish v = tanh(q) . w as V
-// so that on every SIMD one wave's L2 waits, epilogues and owner work run under the other wave's MFMAs (the matrix pipe
-// is per SIMD and shared by its two waves).  A group = 8 members x 2 roles = 16 workgroups works on NT tiles of 16
-// samples; hidden units H_c = [64c, 64c+64); wave w of a workgroup owns the 16 features 64c + 16w ...
+//       cst  (owner waves, behind P2) cost integrals of the evaluation just answered; z = A s, A^T z + c for the next owner's step
+// so that one wave's L2 waits, barriers and LDS latencies run under the other wave's work.  (Only waits: an fp32 MFMA occupies the
+// SIMD's vector ALU -- a co-resident wave makes no VALU progress while the other streams MFMAs, tools/micro/ -- so every VALU
+// instruction of either role costs MFMA time, and work that is not on the dependency cycle S -> U -> V -> G -> S is placed where
+// its wave would otherwise wait: the cost pass in role B's wait for V, `cst` behind P2 while v travels.)
+// A group = 8 members x 2 roles = 16 workgroups works on NT <= 4 tiles of 16 samples; hidden units H_c = [64c, 64c+64); wave w of
+// a workgroup owns the 16 features 64c + 16w ...; sample 2c + j of a tile is owned by member c (wave (2t + j) & 3 of its role A).
 //
 // Matrix work: v_mfma_f32_16x16x4_f32, weights as the A operand (M = 16 features), samples as N = 16; a lane's 4 result
 // registers are 4 consecutive features of one sample = the B fragment of the next GEMM.  Every exchange buffer is a
-// list of 1 KiB fragments [64 lanes][4 floats].
+// list of 1 KiB fragments [64 lanes][4 floats].  A workgroup GATHERS a tile's fragments from L2 into an LDS staging buffer (each
+// wave its share, all requests of a poll in flight together, sc1 loads: never through the CU's L1), one barrier, and the four waves
+// multiply from LDS (ring of 4 ds_read_b128, 3 k-blocks ahead; 33.8 cycles per MFMA).  Stores and LDS reads that only have to be
+// ISSUED before a product ends (slot resets, the epilogue's bias vectors, the tanh(o) request) sit inside the MFMA stream (du_gemm_lds's
+// mid hook): they issue in the MFMAs' shadow instead of on the path.
 //
-// B operands are STREAMED FROM L2 INTO REGISTERS by every wave for itself (a ring of DU_R fragments in flight, sc1 loads:
-// never through the CU's L1): no LDS staging, no workgroup barrier on the exchange path, and a wave starts multiplying as
-// soon as the first fragments have arrived.  Role A executes no s_barrier after its prologue; role B one per tile (the y
-// fragments of its four waves meet in LDS) and two for the cost pass.
-//
-// Exchange protocol: DATA-TAGGED, no flags.  Every buffer exists twice (parity of the evaluation counter e) and starts as
-// all-ones words (0xFFFFFFFF: a NaN pattern no result has).  A producer stores a fragment into the parity-e buffer; a
-// consumer loads it and re-loads while any word of its 16 bytes is still the sentinel (bounded: on a timeout an error word
-// is set, every wave stops waiting, the host raises).  Slots are RESET (sentinel stores into the other parity) by their
-// producer at a point chosen so that
+// Exchange protocol: DATA-TAGGED, no flags.  Every buffer exists twice (parity of the evaluation counter e; the cost scalars QW three
+// times) and starts as all-ones words (0xFFFFFFFF: a NaN pattern no result has).  A producer stores a fragment into the parity-e
+// buffer; a consumer loads it and re-loads while any word of its 16 bytes is still the sentinel (bounded: on a timeout an error word
+// is set, every wave stops waiting, the host raises).  Slots are RESET (sentinel stores) by their producer at a point chosen so that
 //   (H2) every reader of the old contents has finished: the reset of X(e-1) is issued only after the producer has SEEN a
 //        fragment of evaluation e whose existence implies it (the evaluation is an all-to-all dependency cycle
 //        S -> U -> V -> G -> S), and
 //   (H1) no reader can see the old contents again: between the reset and the reader's first poll of that slot (one
-//        evaluation later) the reader has consumed a payload that the same producer wave stored AFTER the reset and after
-//        an intervening `s_waitcnt vmcnt(0)` (vmcnt retires loads and stores in issue order; every streamed GEMM ends in
-//        vmcnt(0)).  Placement: U, TH and V are reset in the P1 epilogue (V one phase early on purpose: its readers, the
-//        role-B waves, consume nothing else from role A before they poll V again); G is reset inside P3 right after its
-//        first V fragment has been validated (so P3's closing vmcnt(0) lies between the reset and the G payload); S and
-//        the cost scalars QW are reset with the next payload (their readers consume U / V / G of the same wave first).
+//        evaluation later) the reader has consumed -- directly or through another workgroup -- a payload that the same producer
+//        wave stored AFTER the reset and after an intervening `s_waitcnt vmcnt(0)` (vmcnt retires loads and stores in issue order).
+//   Placement: U, TH and V of evaluation e-1 are reset inside P2 of evaluation e (S(e) is staged: every owner has consumed G(e-1),
+//   so every role B has finished P4(e-1); P2's vmcnt(0) in front of the V store lies between); G(e-1) inside P3 of evaluation e (V(e)
+//   is complete: every owner published S(e) after reading G(e-1); the tanh(o) wait lies between the reset and the G payload); S(e-1)
+//   with the payload S(e) (same wave, other parity; its readers consume U / V / G first); the cost scalars QW(e-2) inside P3 of
+//   evaluation e: the owner integrates the costs of evaluation e-1 behind P2 of evaluation e -- possibly after V(e) is complete --
+//   so a slot is only reset once S(e) proves that its reader is done, and there are three of them (e mod 3).
 // A group whose 16 workgroups report the same XCC id keeps payloads in that XCD's L2 (plain stores); any other group
-// writes through (sc1).  Placement-independent; workgroups of a group share blockIdx % 8 (speed only).
+// writes through (sc1).  Placement-independent; workgroups of a group share blockIdx % 8, and the CU census at kernel start makes
+// the two workgroups of a CU role A and role B of the SAME member (speed only).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
