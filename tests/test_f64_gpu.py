@@ -87,7 +87,9 @@ def test_f64_every_initprob_problem_against_the_oracle_in_double(name, training)
 
 
 @pytest.mark.parametrize("nTh,m,n,stepper,tspan", [(4, 64, 1, "rk4", [0.0, 1.0]), (3, 100, 5, "rk1", [0.0, 1.0]),
-                                                    (2, 512, 7, "rk4", [0.25, 0.9]), (2, 130, 1030, "rk4", [0.0, 1.0])])
+                                                    (2, 512, 7, "rk4", [0.25, 0.9]), (2, 130, 1030, "rk4", [0.0, 1.0]),
+                                                    # wide layers (m > 256: the register-tiled products) with ragged row blocks and k tails
+                                                    (2, 300, 9, "rk4", [0.0, 1.0]), (3, 260, 1025, "rk4", [0.0, 1.0]), (2, 257, 3, "rk1", [0.0, 0.5])])
 def test_f64_depths_widths_steppers_and_ragged_batches(nTh, m, n, stepper, tspan):
     torch.manual_seed(3)
     prob, x0, _, _ = na.initProb("midcross4", n, 4, 0.5, ALPH, lambda t: t.to(F64).to(DEV))
@@ -123,7 +125,7 @@ def test_f64_refuses_mixed_precision_and_training():
         na.OCflow(x64, net64, prob, [0.0, 1.0], 4, "rk4", g.meta["alph"])            # autograd in double
 
 
-@pytest.mark.parametrize("nTh,m,n", [(2, 24, 1), (3, 40, 7), (4, 64, 33), (2, 512, 1030)])
+@pytest.mark.parametrize("nTh,m,n", [(2, 24, 1), (3, 40, 7), (4, 64, 33), (2, 512, 1030), (2, 300, 17), (3, 263, 5)])
 def test_f64_phi_value_and_gradient_against_the_oracle_in_double(nTh, m, n):
     """Phi.forward / Phi.getGrad in double (src/Phi.py:91-138) on random points s = [x, t]"""
     d = 8

@@ -125,3 +125,20 @@ def test_jit_modes_and_the_background_cache(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "_jit_libs", {})
     monkeypatch.setattr(_lib, "_jit_started", set())
     assert _lib.lib_for(8, 96, 2, 9, 4) is _lib.lib()
+
+
+def test_contract_splits_the_rows_of_wide_products_and_keeps_the_sum():
+    """neuraloc_amd/train.py _contract: wide outputs (the 512-wide network's weight gradients) are cut into row slabs, one batched
+    GEMM, fixed-order sum; the result is X' Y whatever the slab count (host tensors take the same torch path)"""
+    from neuraloc_amd.train import _contract
+    g = torch.Generator().manual_seed(11)
+    for K, m, n in ((16 * 8192, 130, 161), (8192 * 2 + 8, 200, 140), (1000, 160, 150)):      # 16 slabs; 8 slabs (K % 16 != 0); too short to split
+        X = torch.randn(K, m, generator=g)
+        Y = torch.randn(K, n, generator=g)
+        want = (X.double().t() @ Y.double())
+        got = _contract(X, Y)
+        assert got.shape == (m, n)
+        assert float((got.double() - want).abs().max()) <= 2e-5 * (K ** 0.5)
+        acc = _contract(X, Y, got.clone())
+        assert float((acc.double() - 2 * want).abs().max()) <= 4e-5 * (K ** 0.5)
+        assert torch.equal(_contract(X, Y), got)                       # run-to-run identical
