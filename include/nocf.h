@@ -188,6 +188,28 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
                          float* PHIb, float* lam0, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Activation record (optional, training of two-layer networks that the split-role kernel takes: m = 512, point-agent problems).
+ * nocf_rollout_record_act_f32 = nocf_rollout_record_f32 that also stores, for every RK evaluation and sample, the activations of
+ * grad Phi -- u0 = sigma(o), tanh(o), tanh(q), a = w + hN K1' v ([nt*nstage, n, m] each) and grad Phi ([nt*nstage, n, d+1]) -- into
+ *   act_rec  device [nocf_activation_record_floats(...)] floats (four sections of nt*nstage*n*m, one of nt*nstage*n*(d+1)); NULL: no record
+ *   recorded host int32: 1 when the kernel this call launched wrote the record (only the split-role kernel does), else 0
+ * nocf_rollout_bwd_act_f32 = nocf_rollout_bwd_f32 that, given a record the forward launch WROTE (recorded == 1), loads these
+ * activations instead of re-running grad Phi's forward sweep at every evaluation (four of its eight GEMM phases and the weights they
+ * stream; the terminal evaluation is still recomputed).  act_rec NULL: exactly nocf_rollout_bwd_f32.
+ * nocf_activation_record_floats returns 0 for shapes without a recording kernel (pass NULL then).
+ * (src/OCflow.py:7-95 forward, trainOC.py:172-173 backward: what autograd keeps as saved tensors of the unrolled graph)
+ */
+size_t nocf_activation_record_floats(int32_t d, int32_t m, int32_t nTh, int64_t n, int32_t nt, int32_t stepper);
+int nocf_rollout_record_act_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                                double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                                float* z_out, float* persample, float* cost_sums, float* s_all, float* act_rec, int32_t* recorded,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int nocf_rollout_bwd_act_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                             const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                             float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                             float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The same adjoint for SMALL networks (nTh = 2, m <= 32, d+1 <= 32, Cross2D agents: the shapes the lane kernel of
  * nocf_rollout_f32 takes), one wavefront per sample with every weight-gradient row in registers: nothing is streamed and
  * nothing is left to contract.  Returns NOCF_E_SHAPE for any other shape (use nocf_rollout_bwd_f32 then).

@@ -143,4 +143,8 @@ struct RollArgs {
     float* z_out; float* persample; float* zFull; float* ctrlFull; int cdim;
     unsigned long long* stamps;
     float* sAll;                     // training: stage inputs s=[x,t] of every RK evaluation, [nt*nstage][n][d+1]
+    // training, optional: the activation record (include/nocf.h, nocf_rollout_record_act_f32).  Four sections of actRows x m floats
+    // (u0 = sigma(o), tanh(o), tanh(q), a = w + hN K1' v of every RK evaluation and sample) and one of actRows x (d+1) (grad Phi);
+    // actRows = nt * nstage * n.  Only the split-role kernel writes it.
+    float* act; long actRows;
 };

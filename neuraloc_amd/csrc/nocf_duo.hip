@@ -675,6 +675,12 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 <= d) dst[pi + e4] = xs[e4];
                 }
+                // ... and, with an activation record, grad Phi of evaluation e-1 (index e-2)
+                if (REC && ra.act && own_row(t, j) < ra.n) {
+                    float* dst = ra.act + 4 * ra.actRows * (64 * DU_G) + (((long)(e - 2)) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 1);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 <= d) dst[pi + e4] = gs[e4];
+                }
             }
             DTL(40 * t + 2);
             // (behind the store: off the critical path) what the cost part needs, parked in LDS -- P1 and P2 run between the two
@@ -835,6 +841,14 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
                         du_st(g, vb, xU + fo, sg);
                         du_st(g, vb, xT + fo, th);
+                        if (REC && ra.act && !fin) {                   // activation record: 4 features of sample lane & 15 (64-byte runs per sample)
+                            const long rw = rowg + 16 * t + (lane & 15);
+                            if (rw < ra.n) {
+                                float* dst = ra.act + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G) + 64 * member + 16 * wave + 4 * slot;
+                                *reinterpret_cast<float4*>(dst) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+                                *reinterpret_cast<float4*>(dst + ra.actRows * (64 * DU_G)) = make_float4(th[0], th[1], th[2], th[3]);
+                            }
+                        }
                     }
                     DTL(40 * t + 7);
 #ifdef NOCF_STAMPS
@@ -864,14 +878,21 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         asm volatile("" : "+v"(v) : "v"(b1s.x), "v"(wvs.x));
                         DTL(40 * t + 16);
 #endif
+                        f32x4 tq;
 #pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) v[e4] = tanh_fast(acc[e4] + b1v[e4]) * wv[e4];
+                        for (int e4 = 0; e4 < 4; ++e4) { tq[e4] = tanh_fast(acc[e4] + b1v[e4]); v[e4] = tq[e4] * wv[e4]; }
 #ifdef NOCF_STAMPS
                         asm volatile("" : "+v"(v));
                         DTL(40 * t + 17);
 #endif
                         du_st(g, vb, xV + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, v);
                         DTL(40 * t + 12);
+                        if (REC && ra.act && !fin) {                   // activation record: tanh(q)
+                            const long rw = rowg + 16 * t + (lane & 15);
+                            if (rw < ra.n)
+                                *reinterpret_cast<float4*>(ra.act + 2 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
+                                                           + 64 * member + 16 * wave + 4 * slot) = make_float4(tq[0], tq[1], tq[2], tq[3]);
+                        }
                         if (fin) {
                             // w . u_1 = w . (u_0 + hN sigma(q)) over this wave's 16 features (src/Phi.py:91-96): own u_0 fragment from the staged tile
                             const float4 u4 = L4[(DA_UF >> 2) + (4 * member + wave) * 64 + lane];
@@ -1052,10 +1073,17 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the resets above have landed: see there)
                 {
                     const f32x4 th = du_f(thv);
+                    const float4 a4 = make_float4(wvs.x + hN * acc[0], wvs.y + hN * acc[1], wvs.z + hN * acc[2], wvs.w + hN * acc[3]);
                     float4 y;
-                    y.x = th[0] * (wvs.x + hN * acc[0]); y.y = th[1] * (wvs.y + hN * acc[1]);
-                    y.z = th[2] * (wvs.z + hN * acc[2]); y.w = th[3] * (wvs.w + hN * acc[3]);
+                    y.x = th[0] * a4.x; y.y = th[1] * a4.y;
+                    y.z = th[2] * a4.z; y.w = th[3] * a4.w;
                     L4[(DB_YF >> 2) + wave * 64 + lane] = y;
+                    if (REC && ra.act && !fin) {                       // activation record: a = w + hN K1' v
+                        const long rw = rowg + 16 * t + (lane & 15);
+                        if (rw < ra.n)
+                            *reinterpret_cast<float4*>(ra.act + 3 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
+                                                       + 64 * member + 16 * wave + 4 * slot) = a4;
+                    }
                 }
                 DTL(40 * t + 27);
                 // (in front of the barrier: they do not depend on y, and the other waves' epilogues cover them)

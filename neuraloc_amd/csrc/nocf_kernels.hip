@@ -1834,7 +1834,9 @@ int nocf_ctrl_dim(const NocfProb* prob, int32_t d) {
 static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
                         double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
                         float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
-                        void* workspace, size_t workspace_bytes, void* stream, float* s_all) {
+                        void* workspace, size_t workspace_bytes, void* stream, float* s_all,
+                        float* act = nullptr, int32_t* act_recorded = nullptr) {
+    if (act_recorded) *act_recorded = 0;
     int rc = check_phi(phi);
     if (rc) return rc;
     if (!x || !alph || !workspace) return NOCF_E_NULL;
@@ -1859,6 +1861,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     ra.cdim = nocf_ctrl_dim(prob, phi->d);
     ra.stamps = g_stamp_buf;
     ra.sAll = s_all;
+    ra.act = nullptr; ra.actRows = 0;             // (only the split-role kernel records activations: set below)
     hipError_t e;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const unsigned* errp = nullptr;
@@ -1900,8 +1903,11 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         if (g_prof_on) {
             if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
         }
+        if (act && s_all) { ra.act = act; ra.actRows = (long)nt * ((stepper == NOCF_RK4) ? 4 : 1) * n; }
         rc = duo_launch(phi, pb, ra, ws, workspace_bytes, st, &errp, env_int("NOCF_DEBUG", 0), g_prof_on ? ev0 : nullptr, g_prof_on ? ev1 : nullptr);
+        ra.act = nullptr; ra.actRows = 0;
         if (rc == 0) {
+            if (act && s_all && act_recorded) *act_recorded = 1;
             g_last_kernel = "rollout_duo_kernel";
             g_last_errp = errp;
             if (g_prof_on) g_prof_events.emplace_back(ev0, ev1);
@@ -2019,10 +2025,52 @@ int nocf_rollout_record_f32(const NocfPhi* phi, const NocfProb* prob, const floa
                         workspace, workspace_bytes, stream, s_all);
 }
 
+size_t nocf_activation_record_floats(int32_t d, int32_t m, int32_t nTh, int64_t n, int32_t nt, int32_t stepper) {
+#ifdef NOCF_JIT_ONLY
+    (void)d; (void)m; (void)nTh; (void)n; (void)nt; (void)stepper;
+    return 0;
+#else
+    size_t dummy = 0;
+    if (nTh != 2 || n < 1 || nt < 1 || (stepper != NOCF_RK4 && stepper != NOCF_RK1) || env_int("NOCF_DUO", 1) == 0) return 0;
+    if (duo_workspace_bytes(d, m, nTh, d + 1 < 10 ? d + 1 : 10, 1, n, &dummy) != 0) return 0;       // shapes the split-role kernel takes
+    return (size_t)nt * ((stepper == NOCF_RK4) ? 4 : 1) * (size_t)n * (size_t)(4 * m + d + 1);
+#endif
+}
+
+int nocf_rollout_record_act_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                                double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                                float* z_out, float* persample, float* cost_sums, float* s_all, float* act_rec, int32_t* recorded,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    if (!s_all || !z_out) return NOCF_E_NULL;
+    return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, nullptr, nullptr,
+                        workspace, workspace_bytes, stream, s_all, act_rec, recorded);
+}
+
+static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                            const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                            float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                            float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream);
+
 int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
                          const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
                          float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
                          float* PHIb, float* lam0, void* workspace, size_t workspace_bytes, void* stream) {
+    return rollout_bwd_impl(phi, prob, n, nt, stepper, t1, alph, inv_n, s_all, z_final, hs, Y, Ob, V, Ab, Qb, U0, Wb, Gb, Sx, PHIb, lam0,
+                            nullptr, workspace, workspace_bytes, stream);
+}
+
+int nocf_rollout_bwd_act_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                             const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                             float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                             float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream) {
+    return rollout_bwd_impl(phi, prob, n, nt, stepper, t1, alph, inv_n, s_all, z_final, hs, Y, Ob, V, Ab, Qb, U0, Wb, Gb, Sx, PHIb, lam0,
+                            act_rec, workspace, workspace_bytes, stream);
+}
+
+static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                            const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                            float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                            float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_phi(phi);
     if (rc) return rc;
     if (!alph || !s_all || !z_final || !hs || !Y || !Ob || !V || !Ab || !Qb || !U0 || !Wb || !Gb || !Sx || !PHIb || !workspace)
@@ -2049,6 +2097,7 @@ int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, in
     ba.a0 = alph[0]; ba.a3 = alph[3]; ba.a4 = alph[4]; ba.a5 = alph[5]; ba.inv_n = (float)inv_n;
     ba.Y = Y; ba.Ob = Ob; ba.V = V; ba.Ab = Ab; ba.Qb = Qb; ba.U0 = U0; ba.Wb = Wb; ba.Gb = Gb; ba.Sx = Sx;
     ba.PHIb = PHIb; ba.lam0 = lam0;
+    ba.act = (act_rec && phi->nTh == 2) ? act_rec : nullptr; ba.actRows = (long)nt * ba.nstage * n;
     ba.lstride = ((long)nt * ba.nstage + 2) * n * phi->m;
     const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
     const void* fk = nullptr;

@@ -6,6 +6,7 @@ per-evaluation vectors whose outer products are the weight gradients; the contra
 evaluations are plain library GEMMs (torch.matmul).  Any depth nTh >= 2 (LDS permitting), Cross2D / SwarmTraj / Quadcopter, rk4 / rk1, fp32.
 Only Jc carries a gradient (the 7 logged costs are detached, like the values trainOC prints)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -103,12 +104,21 @@ class _OCflowTrain(torch.autograd.Function):
         _lib.check_errors()
         with torch.cuda.device(dev):
             L = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
-            rc = L.nocf_rollout_record_f32(
+            # activation record (wide two-layer networks on the split-role kernel): the forward keeps u0, tanh(o), tanh(q), a and grad Phi
+            # of every evaluation -- autograd's saved tensors, 2.9 GB for swarm50 -- and the adjoint loads them instead of re-running
+            # grad Phi's forward sweep (NOCF_ACT_REC=0: recompute, as for every other shape)
+            nact = 0 if os.environ.get("NOCF_ACT_REC", "1") in ("0", "") else int(
+                L.nocf_activation_record_floats(int(d), int(net.m), int(net.nTh), int(n), int(nt), _STEPPERS[stepper]))
+            act = torch.empty(nact, device=dev) if nact else None
+            recorded = C.c_int32(0)
+            rc = L.nocf_rollout_record_act_f32(
                                                     C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
                                                     float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
                                                     _lib.ptr(z_out), _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(s_all),
+                                                    _lib.ptr(act), C.byref(recorded),
                                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
-        _lib.check(rc, "nocf_rollout_record_f32")
+        _lib.check(rc, "nocf_rollout_record_act_f32")
+        ctx.act = act if recorded.value else None
         _lib.track_rollout_status(L, dev, "OCflow (training forward)")
         ctx.net, ctx.prob, ctx.tspan, ctx.nt, ctx.stepper, ctx.alph = net, prob, tspan, nt, stepper, list(alph)
         ctx.group = group
@@ -181,14 +191,16 @@ class _OCflowTrain(torch.autograd.Function):
             t[:, rows - n:].zero_()
         PHIb = torch.zeros(n, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents).nocf_rollout_bwd_f32(
+            rc = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents).nocf_rollout_bwd_act_f32(
                                                  C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
                                                  float(ctx.tspan[1]), alph_c, 1.0 / float(ctx.n_total),
                                                  _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs),
                                                  _lib.ptr(Y), _lib.ptr(Ob), _lib.ptr(V), _lib.ptr(Ab), _lib.ptr(Qb),
                                                  _lib.ptr(U0), _lib.ptr(Wb), _lib.ptr(Gb), _lib.ptr(Sx),
-                                                 _lib.ptr(PHIb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
-        _lib.check(rc, "nocf_rollout_bwd_f32")
+                                                 _lib.ptr(PHIb), _lib.ptr(lam0), _lib.ptr(getattr(ctx, "act", None)),
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "nocf_rollout_bwd_act_f32")
+        ctx.act = None
         sT = Sx[(nt * nstage + 1) * n:]                                     # s at the final time (value rows)
         grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": _colsum(Ob)}
         for i in range(1, L + 1):

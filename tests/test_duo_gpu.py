@@ -307,3 +307,32 @@ def test_duo_intermediates_match_the_tile_kernel(n, monkeypatch):
     calm = drift <= 1e-3                                               # on the calm trajectories the running cost L (column d) agrees too
     rel = (zd[calm, d, :] - zt[calm, d, :]).abs() / (1.0 + zt[calm, d, :].abs())
     assert float(rel.max()) <= 2e-3
+
+
+@pytest.mark.parametrize("n,nt,stepper", [(39, 6, "rk4"), (1024, 4, "rk4"), (2049, 3, "rk4"), (100, 7, "rk1")])
+def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt, stepper, monkeypatch):
+    """training of the 512-wide network: the recording forward keeps u0, tanh(o), tanh(q), a and grad Phi of every evaluation (the
+    activation record, nocf_rollout_record_act_f32) and the adjoint loads them instead of re-running grad Phi's forward sweep.  Same
+    forward launch either way (Jc identical), gradients equal up to the rounding of the two forward sweeps; ragged tiles, two tiles
+    per group and a second launch (row offsets of the record) included."""
+    g = load_golden("swarm50")
+    m = g.meta
+    x = (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 5)).contiguous().to(DEV)
+    out = {}
+    for rec in ("1", "0"):
+        monkeypatch.setenv("NOCF_ACT_REC", rec)
+        net = make_net(g, DEV).train()
+        prob = make_prob(g, DEV, training=True)
+        xx = x.clone().requires_grad_(True)
+        Jc, _ = na.OCflow(xx, net, prob, [0.0, 1.0], nt, stepper, m["alph"])
+        assert _kernel() == "rollout_duo_kernel"
+        Jc.backward()
+        torch.cuda.synchronize()
+        na.check_errors(sync=True)
+        out[rec] = (float(Jc.detach()), [p.grad.detach().clone() for p in net.parameters()], xx.grad.detach().clone())
+    a, b = out["1"], out["0"]
+    assert a[0] == b[0]
+    for ga, gb in zip(a[1], b[1]):
+        scale = float(gb.abs().max())
+        assert torch.isfinite(ga).all() and float((ga - gb).abs().max()) <= 2e-4 * scale + 1e-12, (float((ga - gb).abs().max()), scale)
+    assert float((a[2] - b[2]).abs().max()) <= 2e-4 * float(b[2].abs().max()) + 1e-12
