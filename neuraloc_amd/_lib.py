@@ -165,6 +165,11 @@ def lib_for(d, m, nTh, r, n_agents):
     if L is not None:
         watch_env(L)
         return L
+    if mode == "auto" and key[1] == 512 and key[2] == 2:
+        # wide two-layer networks run on the split-role kernel of the shipped library (nocf_duo.hip), which a per-shape build does not
+        # contain: specialising the tile kernels for them would be a step down
+        L = _jit_libs[key] = lib()
+        return L
     so = _jit_fresh(key)
     if so is None and mode == "1":
         import subprocess
