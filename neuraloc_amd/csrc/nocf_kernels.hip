@@ -1928,7 +1928,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     // one-CU weight-stationary kernel (nocf_mono.inc): two-layer networks of up to 128 hidden units whose shape has an
     // instantiation (singlequad): no weight stream, no inter-workgroup traffic; also with intermediates
     MonoPlan mpl;
-    const bool use_mono = !s_all && env_int("NOCF_MONO", 1) != 0 &&
+    const bool use_mono = (!s_all || env_int("NOCF_MONO_REC", 1) != 0) && env_int("NOCF_MONO", 1) != 0 &&
                           make_mono_plan(pl, pb.nAgents, &mpl) == 0 && workspace_bytes >= mono_ws_bytes(mpl);
     if (use_mono) {
         mpl.pp.cb = phi->cb;

@@ -30,21 +30,21 @@ _SCRATCH = {}
 
 
 def _contract(X, Y, out=None):
-    """X' Y for row streams X [K, m], Y [K, n] (out += when given).  Small and medium outputs (up to about 128 x 128:
-    everything but the 512-wide swarm50 network) go to the library's two-launch contraction -- a library GEMM with such
-    an output and 10^5..10^6 rows runs on a handful of workgroups (0.4-1.4 ms each); wide ones are library GEMMs
-    (hipBLASLt), split over the rows."""
+    """X' Y for row streams X [K, m], Y [K, n] (out += when given): the weight gradients are sums of outer products over all
+    samples and evaluations, K = 10^5..10^6 rows.  One library GEMM with such an output is a handful of tiles -- a 512 x 512 output
+    64 of them, a quarter of the chip; 128 x 128 four -- so the rows are cut into S slabs (a power of two that divides K, slabs of
+    >= 2048 rows), one BATCHED GEMM (hipBLASLt through torch.bmm) forms the S partial products and a fixed-order sum adds them:
+    swarm50 512 x 512: 2.15 -> 1.17 ms, singlequad 128 x 128: 0.86 (the library's own two-launch contraction) -> 0.25 ms
+    (tools/gemm_splitk_probe.py).  Row counts without such a divisor: the library's two-launch contraction (small outputs) or
+    one GEMM."""
     m, n = X.shape[1], Y.shape[1]
+    K = X.shape[0]
+    S = next((s_ for s_ in (256, 128, 64, 32, 16, 8, 4, 2) if K % s_ == 0 and K // s_ >= 2048 and s_ * m * n <= (1 << 25)), 1)
+    if S > 1 and X.is_contiguous() and Y.is_contiguous():
+        r = torch.bmm(X.view(S, K // S, m).transpose(1, 2), Y.view(S, K // S, n)).sum(0)
+        return r if out is None else out.add_(r)
     if m > 512 or n > 512 or m * n > 128 * 160:
-        # a 512 x 512 (x 151) output is 64 (24) tiles of the library's GEMM: a quarter of the chip.  Split the 10^5..10^6 rows into S
-        # slabs, one batched GEMM, fixed-order sum of the S partial products (swarm50: 2.15 -> 1.19 ms and 0.94 -> 0.45 ms per product,
-        # tools/gemm_splitk_probe.py)
-        K = X.shape[0]
-        S = next((s for s in (16, 8, 4, 2) if K % s == 0 and K // s >= 8192), 1)
-        if S > 1 and X.is_contiguous() and Y.is_contiguous():
-            r = torch.bmm(X.view(S, K // S, m).transpose(1, 2), Y.view(S, K // S, n)).sum(0)
-        else:
-            r = X.t() @ Y
+        r = X.t() @ Y
         return r if out is None else out.add_(r)
     dev = X.device
     sc = _SCRATCH.get(dev)
