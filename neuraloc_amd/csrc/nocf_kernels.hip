@@ -1936,7 +1936,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         hipLaunchKernelGGL(mono_pack_kernel, dim3(64), dim3(256), 0, st, mpl, P, ws);
         const size_t ldsBytes = (size_t)mpl.pp.ldsFloats * 4;
         const void* fk = nullptr;
-#define NOCF_MONO_PICK(M_, D_) if (mpl.KBM == M_ && mpl.KBD == D_) fk = reinterpret_cast<const void*>(rollout_mono_kernel<M_, D_>);
+#define NOCF_MONO_PICK(M_, D_) if (mpl.KBM == M_ && mpl.KBD == D_) fk = s_all ? reinterpret_cast<const void*>(rollout_mono_kernel<M_, D_, true>) : reinterpret_cast<const void*>(rollout_mono_kernel<M_, D_, false>);
         MONO_SHAPES(NOCF_MONO_PICK)
 #undef NOCF_MONO_PICK
         e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes); if (e) return (int)e;
@@ -1946,8 +1946,12 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             (void)hipEventRecord(ev0, st);
         }
         const MonoPlan* mpp = reinterpret_cast<const MonoPlan*>(ws + mpl.pp.oPlan);
+        const bool mono_rec = act && s_all && (phi->m % 16) == 0;              // activation record: the one-CU kernel writes it too
+        if (mono_rec) { ra.act = act; ra.actRows = (long)nt * ((stepper == NOCF_RK4) ? 4 : 1) * n; }
         void* args[] = {(void*)&mpp, (void*)&pb, (void*)&ws, (void*)&ra};
         e = hipLaunchKernel(fk, dim3((int)((n + 15) / 16)), dim3(256), args, ldsBytes, st); if (e) return (int)e;
+        ra.act = nullptr; ra.actRows = 0;
+        if (mono_rec && act_recorded) *act_recorded = 1;
         g_last_kernel = "rollout_mono_kernel";
         e = hipGetLastError();
         if (e) return (int)e;
@@ -2031,8 +2035,12 @@ size_t nocf_activation_record_floats(int32_t d, int32_t m, int32_t nTh, int64_t 
     return 0;
 #else
     size_t dummy = 0;
-    if (nTh != 2 || n < 1 || nt < 1 || (stepper != NOCF_RK4 && stepper != NOCF_RK1) || env_int("NOCF_DUO", 1) == 0) return 0;
-    if (duo_workspace_bytes(d, m, nTh, d + 1 < 10 ? d + 1 : 10, 1, n, &dummy) != 0) return 0;       // shapes the split-role kernel takes
+    if (nTh != 2 || n < 1 || nt < 1 || (stepper != NOCF_RK4 && stepper != NOCF_RK1)) return 0;
+    // shapes with a recording kernel: the split-role kernel's (m = 512) and the one-CU kernel's (m <= 128 in whole 16-blocks, d+1 <= 16;
+    // whether that kernel is taken also depends on the problem: `recorded` of the record call says so)
+    const bool duo = env_int("NOCF_DUO", 1) != 0 && duo_workspace_bytes(d, m, nTh, d + 1 < 10 ? d + 1 : 10, 1, n, &dummy) == 0;
+    const bool mono = env_int("NOCF_MONO", 1) != 0 && env_int("NOCF_MONO_REC", 1) != 0 && m <= 128 && (m % 16) == 0 && d + 1 <= 16 && m > 32;
+    if (!duo && !mono) return 0;
     return (size_t)nt * ((stepper == NOCF_RK4) ? 4 : 1) * (size_t)n * (size_t)(4 * m + d + 1);
 #endif
 }

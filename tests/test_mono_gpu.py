@@ -111,3 +111,37 @@ def test_mono_other_widths_against_oracle(m_, training):
     got = _table(x0, net, prob, [0.0, 1.0], 6, "rk4", alph)
     want = orc.persample_table(x0.cpu(), P, S, [0.0, 1.0], 6, "rk4", alph)
     assert _flips(got, want) == 0, f"m={m_}: {_flips(got, want)} samples off"
+
+
+@pytest.mark.parametrize("n,nt,stepper", [(37, 5, "rk4"), (4096, 3, "rk4"), (100, 6, "rk1")])
+def test_mono_training_forward_records_and_the_activation_record_matches_the_recomputing_adjoint(n, nt, stepper, monkeypatch):
+    """training of singlequad: the one-CU kernel is the recording forward (stage inputs), and with the activation record
+    (NOCF_ACT_REC, default on) it also keeps u0, tanh(o), tanh(q), a and grad Phi so that the adjoint does not re-run grad Phi's
+    forward sweep.  Same forward either way (Jc identical); gradients equal up to the rounding of the two forward sweeps; the
+    recording forward on the tile kernel (NOCF_MONO_REC=0) agrees too."""
+    from neuraloc_amd import _lib
+    g = load_golden("singlequad")
+    m = g.meta
+    x = (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 7)).contiguous().to(DEV)
+    out = {}
+    for tag, env in (("rec", {"NOCF_ACT_REC": "1"}), ("norec", {"NOCF_ACT_REC": "0"}), ("tile", {"NOCF_ACT_REC": "0", "NOCF_MONO_REC": "0"})):
+        for k_ in ("NOCF_ACT_REC", "NOCF_MONO_REC"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        net = make_net(g, DEV).train()
+        prob = make_prob(g, DEV, training=True)
+        xx = x.clone().requires_grad_(True)
+        Jc, _ = na.OCflow(xx, net, prob, [0.0, 1.0], nt, stepper, m["alph"])
+        kern = _lib.lib().nocf_last_rollout_kernel().decode()
+        assert kern == ("rollout_mono_kernel" if tag != "tile" else "rollout_kernel<shape-specialised>"), kern
+        Jc.backward()
+        torch.cuda.synchronize()
+        out[tag] = (float(Jc.detach()), [p.grad.detach().clone() for p in net.parameters()], xx.grad.detach().clone())
+    assert out["rec"][0] == out["norec"][0]
+    assert abs(out["rec"][0] - out["tile"][0]) <= 2e-5 * abs(out["tile"][0])
+    for other, tol in (("norec", 2e-4), ("tile", 2e-3)):
+        for ga, gb in zip(out["rec"][1], out[other][1]):
+            scale = float(gb.abs().max())
+            assert torch.isfinite(ga).all() and float((ga - gb).abs().max()) <= tol * scale + 1e-12, (other, float((ga - gb).abs().max()), scale)
+        assert float((out["rec"][2] - out[other][2]).abs().max()) <= tol * float(out[other][2].abs().max()) + 1e-12
