@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Quick parity + timing probe of the split-role kernel (nocf_duo.hip) against the per-tile kernel and round 2's slab
-kernel on the pretrained swarm50 network.  Diagnostics only.   python tools/duo_probe.py [nt] [n ...]"""
+"""Quick parity + timing probe of the split-role kernel (nocf_duo.hip) against the per-tile kernel on the pretrained swarm50
+network.  Diagnostics only.   python tools/duo_probe.py [nt] [n ...]"""
 import os
 import sys
 import time
@@ -38,7 +38,7 @@ def timeit(x, net, prob, nt, alph, reps=5):
 
 
 def setenv(**kw):
-    for k in ("NOCF_DUO", "NOCF_SLAB", "NOCF_DUO_FAST", "NOCF_DUO_MAP"):
+    for k in ("NOCF_DUO", "NOCF_DUO_FAST", "NOCF_DUO_MAP"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
@@ -56,7 +56,7 @@ def main():
             setenv()
             duo, kd = table(x, net, prob, nt, m["alph"])
             duo2, _ = table(x, net, prob, nt, m["alph"])
-            setenv(NOCF_DUO=0, NOCF_SLAB=0)
+            setenv(NOCF_DUO=0)
             tile, kt = table(x, net, prob, nt, m["alph"])
             off = ((duo.double() - tile.double()).abs() > 1e-3 + 1e-3 * tile.double().abs()).any(dim=1)
             keep = ~off
@@ -71,14 +71,9 @@ def main():
                 t_map = timeit(x, net, prob, nt, m["alph"])
                 setenv(NOCF_DUO_FAST=0)
                 t_wt = timeit(x, net, prob, nt, m["alph"])
-                setenv(NOCF_DUO=0, NOCF_SLAB=2)
-                try:
-                    t_slab = timeit(x, net, prob, nt, m["alph"]) if n <= 1024 else float("nan")
-                except Exception:
-                    t_slab = float("nan")
-                setenv(NOCF_DUO=0, NOCF_SLAB=0)
+                setenv(NOCF_DUO=0)
                 t_tile = timeit(x, net, prob, nt, m["alph"])
-                line += f" | ms/call duo {t_duo:.3f} (map1 {t_map:.3f}, write-through {t_wt:.3f}) slab {t_slab:.3f} tile {t_tile:.3f}"
+                line += f" | ms/call duo {t_duo:.3f} (map1 {t_map:.3f}, write-through {t_wt:.3f}) tile {t_tile:.3f}"
             print(line, flush=True)
             if off.any():
                 idx = torch.nonzero(off).flatten()[:4].tolist()
