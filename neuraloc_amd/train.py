@@ -109,7 +109,12 @@ class _OCflowTrain(torch.autograd.Function):
             # grad Phi's forward sweep (NOCF_ACT_REC=0: recompute, as for every other shape)
             nact = 0 if os.environ.get("NOCF_ACT_REC", "1") in ("0", "") else int(
                 L.nocf_activation_record_floats(int(d), int(net.m), int(net.nTh), int(n), int(nt), _STEPPERS[stepper]))
-            act = torch.empty(nact, device=dev) if nact else None
+            act = None
+            if nact:
+                try:
+                    act = torch.empty(nact, device=dev)
+                except torch.OutOfMemoryError:                     # the record is an optimisation: without it the adjoint recomputes
+                    act = None
             recorded = C.c_int32(0)
             rc = L.nocf_rollout_record_act_f32(
                                                     C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
