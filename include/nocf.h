@@ -210,6 +210,41 @@ int nocf_rollout_bwd_act_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
                              float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Training tape + split-role adjoint (round 4; the path trainOC.py:172-174 takes for the networks the split-role kernel runs: m = 512,
+ * nTh = 2, point-agent problems).  The tape is the activation record above with the TERMINAL evaluation as one more block and three
+ * scalars per evaluation -- everything autograd would keep of the unrolled graph of src/OCflow.py:7-95 -- laid out as
+ *     R = (nt*nstage + 1) * n rows, block e < nt*nstage = RK evaluation e, block nt*nstage = the terminal evaluation (src/OCflow.py:58-64)
+ *     [0, 4 R m)                  u0 | tanh(o) | tanh(q) | a          four sections [R, m]
+ *     [4 R m, + R (d+1))          grad Phi                            [R, d+1]   (padded to a multiple of 4 floats)
+ *     then n m                    u_1 of the terminal evaluation      [n, m]
+ *     then 4 R                    (dPhi/dt - H, q, w, 0) per row; terminal block: (Phi - alph0 G, 0, 0, 0)
+ * nocf_tape_floats: size of that buffer in floats, 0 when the shape has no tape-writing kernel (use the record calls above then).
+ * nocf_rollout_tape_f32 = nocf_rollout_record_f32 with s_all of nt*nstage + 1 blocks (the last: [z(T), t1]) and the tape;
+ *   *recorded = 1 when the launched kernel wrote the tape (else only the first nt*nstage blocks of s_all are written: fall back to
+ *   nocf_rollout_bwd_f32).
+ * nocf_rollout_bwd_tape_f32: the adjoint of the discrete scheme on the split-role layout.  Writes the row vectors whose outer products
+ *   are the weight gradients, one row per (block, sample) as on the tape (the value's rows of nocf_rollout_bwd_f32 are folded into the
+ *   terminal block):
+ *     Y = tanh(o).a, Ab = abar0, Wb = dw row, Qb = qbar, Ob = obar   device [R, m];   Gb = gbar   device [R, d+1]
+ *   so that, with the tape's U0 = u0, TH1 = tanh(q) and Sx = s_all,
+ *     dK0 = Y'Gb + Ob'Sx,  db0 = colsum Ob,  dK1 = diag(w) TH1'Ab + Qb'U0,  db1 = colsum Qb,  dw = colsum Wb,
+ *     dc.weight = colsum Gb + phib'sT,  d(A'A) = Gb'Sx + (sT.phib)'sT / 2,  phib = alph4 sign(tape scalar of the terminal block) / n_total.
+ *   lam0 device [n, d] = dJc/dx0 (nullable).  Returns NOCF_E_SHAPE when the shape / problem / residency does not qualify (nothing launched).
+ *   A timed-out exchange is reported like the forward's (nocf_last_rollout_status_async); nocf_poison_if_failed_f32 turns a buffer
+ *   into NaN on the stream if the last launch of this thread failed (call it on the gradients before they are used).
+ */
+size_t nocf_tape_floats(int32_t d, int32_t m, int32_t nTh, int64_t n, int32_t nt, int32_t stepper);
+int nocf_rollout_tape_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                          double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                          float* z_out, float* persample, float* cost_sums, float* s_all, float* tape, int32_t* recorded,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
+                              const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                              const float* tape, float* Y, float* Ab, float* Wb, float* Qb, float* Ob, float* Gb, float* lam0,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int nocf_poison_if_failed_f32(float* buf, int64_t count, void* stream);
+
+/*
  * The same adjoint for SMALL networks (nTh = 2, m <= 32, d+1 <= 32, Cross2D agents: the shapes the lane kernel of
  * nocf_rollout_f32 takes), one wavefront per sample with every weight-gradient row in registers: nothing is streamed and
  * nothing is left to contract.  Returns NOCF_E_SHAPE for any other shape (use nocf_rollout_bwd_f32 then).

@@ -147,4 +147,9 @@ struct RollArgs {
     // (u0 = sigma(o), tanh(o), tanh(q), a = w + hN K1' v of every RK evaluation and sample) and one of actRows x (d+1) (grad Phi);
     // actRows = nt * nstage * n.  Only the split-role kernel writes it.
     float* act; long actRows;
+    // training tape for the split-role adjoint (nocf_duo_bwd.inc; include/nocf.h, nocf_rollout_tape_f32): the record above with the
+    // TERMINAL evaluation as one more block (actRows = (nt * nstage + 1) * n; sAll then has that block too), plus u_1 = u_0 + hN sigma(q)
+    // of the terminal evaluation ([n][m]) and four scalars per evaluation and sample ([actRows][4]: dPhi/dt - H, the x-only cost terms
+    // q and w of that state, 0; terminal block: Phi - alph0 G, 0, 0, 0).  Null: no tape.
+    float* tapeU1; float* tapeSc;
 };

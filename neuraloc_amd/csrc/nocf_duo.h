@@ -19,5 +19,17 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra, float*
 
 long duo_rows_per_launch(void);
 
+// The adjoint on the same layout (nocf_duo_bwd.inc): same return convention as duo_launch.  All pointers are device memory; the
+// tape is the one the recording forward (RollArgs::act / tapeU1 / tapeSc with the terminal block) wrote for the same rows.
+struct DuoBwdHost {
+    const float *s_all, *z_final, *hs, *tape, *tapeU1, *tapeSc;
+    long n; int nt, stepper;
+    float a0, a3, a4, a5, inv_n;
+    float *Y, *Ab, *Wb, *Qb, *Ob, *Gb, *lam0;
+    unsigned long long* stamps;
+};
+int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, float* ws, size_t ws_bytes, hipStream_t st,
+                   const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1);
+
 // NOCF_* knob, read from the environment once and cached (nocf_kernels.hip); nocf_debug_reload_env() drops the cache
 int nocf_env_int(const char* name, int dflt);

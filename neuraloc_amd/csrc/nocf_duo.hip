@@ -409,11 +409,12 @@ __device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, in
 
 // byte offsets of the exchange kinds inside a group's area (functions of NT), all pinned in scalar registers by the kernel
 struct DXOff { int S, U, T, V, G, Q, P; };
-__host__ __device__ inline long duo_x_layout(int NT, DXOff* o) {
+// (bwd: the adjoint's layout -- the Q area holds the physics term of two own samples per member, 2 x 160 floats, instead of 2 x 2 scalars)
+__host__ __device__ inline long duo_x_layout(int NT, DXOff* o, bool bwd = false) {
     long x = 0;
     auto take = [&](long nfl) { const long at = x; x += (nfl + 63) / 64 * 64; return at; };
     const long s = take(2L * NT * DU_KBD * 256), u = take(2L * NT * DU_KBM * 256), t = take(2L * NT * DU_KBM * 256), v = take(2L * NT * DU_KBM * 256);
-    const long gg = take(2L * NT * DU_G * DU_KBD * 256), q = take(3L * NT * DU_G * 4), p = take((long)NT * DU_G * 4 * 16);
+    const long gg = take(2L * NT * DU_G * DU_KBD * 256), q = take(3L * NT * DU_G * (bwd ? 320 : 4)), p = take((long)NT * DU_G * 4 * 16);
     if (o) { o->S = (int)(s * 4); o->U = (int)(u * 4); o->T = (int)(t * 4); o->V = (int)(v * 4); o->G = (int)(gg * 4); o->Q = (int)(q * 4); o->P = (int)(p * 4); }
     return x;                                      // floats per group
 }
@@ -669,8 +670,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     else L4[(sbase + DS_ZA + pi) >> 2] = make_float4(zA[0], zA[1], zA[2], zA[3]);
                 }
                 L4[(sbase + DS_XS + pi) >> 2] = make_float4(xs[0], xs[1], xs[2], xs[3]);
-                // training: the stage input of evaluation e (index e-1); the terminal evaluation is not recorded
-                if (REC && ra.sAll && e <= ra.nt * nstage && own_row(t, j) < ra.n) {
+                // training: the stage input of evaluation e (index e-1); the terminal evaluation is recorded only on a tape
+                if (REC && ra.sAll && e <= ra.nt * nstage + (ra.tapeSc ? 1 : 0) && own_row(t, j) < ra.n) {
                     float* dst = ra.sAll + (((long)(e - 1)) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 1);
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 <= d) dst[pi + e4] = xs[e4];
@@ -722,6 +723,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 float Lg = 0.5f * sp2 + Qs;
                 if (cWantW) Lg = Lg + cAlphW * Wv;
                 const float H = -Lg + sp2;
+                if (REC && ra.tapeSc && lane == 0 && own_row(t, j) < ra.n)      // tape: dPhi/dt - H and the x-only terms of evaluation e-1 (index e-2)
+                    *reinterpret_cast<float4*>(ra.tapeSc + (((long)(e - 2)) * rr.n_total + rr.row0 + own_row(t, j)) * 4) = make_float4(gt - H, q_, w_, 0.f);
                 const float val = (lane == 0) ? Lg : (lane == 1) ? fabsf(gt - H) : (lane == 2) ? (PD == 2 ? Qs : q_) : Wv;
                 const float K = hs * val;
                 float* cz = lds + sbase + DS_CZ + lane;                     // [0..3] value, [4..7] RK accumulator
@@ -841,7 +844,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
                         du_st(g, vb, xU + fo, sg);
                         du_st(g, vb, xT + fo, th);
-                        if (REC && ra.act && !fin) {                   // activation record: 4 features of sample lane & 15 (64-byte runs per sample)
+                        if (REC && ra.act && (!fin || ra.tapeSc)) {    // activation record: 4 features of sample lane & 15 (64-byte runs per sample)
                             const long rw = rowg + 16 * t + (lane & 15);
                             if (rw < ra.n) {
                                 float* dst = ra.act + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G) + 64 * member + 16 * wave + 4 * slot;
@@ -887,7 +890,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 #endif
                         du_st(g, vb, xV + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, v);
                         DTL(40 * t + 12);
-                        if (REC && ra.act && !fin) {                   // activation record: tanh(q)
+                        if (REC && ra.act && (!fin || ra.tapeSc)) {    // activation record: tanh(q)
                             const long rw = rowg + 16 * t + (lane & 15);
                             if (rw < ra.n)
                                 *reinterpret_cast<float4*>(ra.act + 2 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
@@ -897,9 +900,13 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                             // w . u_1 = w . (u_0 + hN sigma(q)) over this wave's 16 features (src/Phi.py:91-96): own u_0 fragment from the staged tile
                             const float4 u4 = L4[(DA_UF >> 2) + (4 * member + wave) * 64 + lane];
                             const float u0[4] = {u4.x, u4.y, u4.z, u4.w};
-                            float pr = 0.f;
+                            float pr = 0.f, u1[4];
 #pragma unroll
-                            for (int e4 = 0; e4 < 4; ++e4) pr += wv[e4] * (u0[e4] + hN * sigma_act(acc[e4] + b1v[e4]));
+                            for (int e4 = 0; e4 < 4; ++e4) { u1[e4] = u0[e4] + hN * sigma_act(acc[e4] + b1v[e4]); pr += wv[e4] * u1[e4]; }
+                            if (REC && ra.tapeU1) {                    // tape: u_1 of the terminal evaluation (the value's dw row)
+                                const long rw = rowg + 16 * t + (lane & 15);
+                                if (rw < ra.n) *reinterpret_cast<float4*>(ra.tapeU1 + (rr.row0 + rw) * (64 * DU_G) + 64 * member + 16 * wave + 4 * slot) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                            }
                             pr += __shfl_xor(pr, 16); pr += __shfl_xor(pr, 32);
                             if (lane < 16) {
                                 const unsigned pu = __float_as_uint(pr);
@@ -950,6 +957,18 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 ph = sum64(lane < 32 ? __uint_as_float(u) : 0.f);
             }
             const long row = own_row(t, j);
+            if (REC && ra.tapeSc && row < ra.n) {               // tape: grad Phi and Phi - alph0 G of the terminal evaluation (block nt * nstage)
+                const long blk = (long)ra.nt * nstage;
+                if (pact) {
+                    float* dst = ra.act + 4 * ra.actRows * (64 * DU_G) + (blk * rr.n_total + rr.row0 + row) * (d + 1);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 <= d) dst[pi + e4] = gs[e4];
+                }
+                if (lane == 0) {
+                    const float phi = ph + lds[sbase + DS_PHX + 1] + lds[sbase + DS_PHX] + dp.cb;
+                    *reinterpret_cast<float4*>(ra.tapeSc + (blk * rr.n_total + rr.row0 + row) * 4) = make_float4(phi - ra.a0 * cG, 0.f, 0.f, 0.f);
+                }
+            }
             if (row < ra.n) {
                 if (lane == 0 && ra.persample) {
                     const float phi = ph + lds[sbase + DS_PHX + 1] + lds[sbase + DS_PHX] + dp.cb;
@@ -1078,7 +1097,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     y.x = th[0] * a4.x; y.y = th[1] * a4.y;
                     y.z = th[2] * a4.z; y.w = th[3] * a4.w;
                     L4[(DB_YF >> 2) + wave * 64 + lane] = y;
-                    if (REC && ra.act && !fin) {                       // activation record: a = w + hN K1' v
+                    if (REC && ra.act && (!fin || ra.tapeSc)) {        // activation record: a = w + hN K1' v
                         const long rw = rowg + 16 * t + (lane & 15);
                         if (rw < ra.n)
                             *reinterpret_cast<float4*>(ra.act + 3 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
@@ -1138,6 +1157,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     }
 }
 
+#include "nocf_duo_bwd.inc"
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1145,7 +1166,7 @@ static int du_env_int(const char* name, int dflt) { return nocf_env_int(name, df
 
 long duo_rows_per_launch(void) { return 32L * 16 * DU_NTMAX; }
 
-static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out) {
+static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false) {
     if (nTh != 2 || m != 64 * DU_G || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
     DuoPlan dp;
     memset(&dp, 0, sizeof(dp));
@@ -1155,7 +1176,7 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
     dp.NT = (int)((ntiles + dp.ngroups - 1) / dp.ngroups);
     if (dp.NT > DU_NTMAX) return NOCF_E_SHAPE;
     dp.hN = 1.0f;
-    const int ldsA = DA_T + 2 * dp.NT * DS_STRIDE, ldsB = DB_END;
+    const int ldsA = DA_T + 2 * dp.NT * (bwd ? DSB_STRIDE : DS_STRIDE), ldsB = DB_END;
     dp.ldsFloats = std::max(ldsA, ldsB);
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
     long o = 0;                                                                    // floats
@@ -1173,7 +1194,7 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
     dp.oCW = o; o += DU_DP;
     o = (o + 63) / 64 * 64;
     dp.oX = o;
-    dp.xStride = duo_x_layout(dp.NT, nullptr);
+    dp.xStride = duo_x_layout(dp.NT, nullptr, bwd);
     *out = dp;
     return 0;
 }
@@ -1181,10 +1202,12 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
 static size_t duo_ws_bytes_of(const DuoPlan& dp) { return (size_t)(dp.oX + (long)dp.ngroups * dp.xStride) * sizeof(float); }
 
 int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size_t* bytes) {
-    DuoPlan dp;
+    DuoPlan dp, db;
     const int rc = make_duo_plan(d, m, nTh, r, n_agents, std::min<long>(n, duo_rows_per_launch()), &dp);
     if (rc) return rc;
-    if (bytes) *bytes = duo_ws_bytes_of(dp);
+    size_t b = duo_ws_bytes_of(dp);
+    if (make_duo_plan(d, m, nTh, r, n_agents, std::min<long>(n, duo_rows_per_launch()), &db, true) == 0) b = std::max(b, duo_ws_bytes_of(db));   // (the adjoint's exchange area is larger)
+    if (bytes) *bytes = b;
     return 0;
 }
 
@@ -1253,6 +1276,67 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
             (void)hipMemcpy(w, ws + dp.oErr, 8, hipMemcpyDeviceToHost);
             fprintf(stderr, "[nocf] duo kernel: error word 0x%x, %u of %d workgroups paired by the CU census\n", w[0], w[1], 16 * dp.ngroups);
         }
+    }
+    *errp = reinterpret_cast<const unsigned*>(ws) + dp0.oErr;
+    return 0;
+}
+
+// ---- the adjoint (nocf_duo_bwd.inc).  Same plan, same images, same residency rule as the forward.
+template <int PD>
+static const void* duo_bwd_fn() { return reinterpret_cast<const void*>(rollout_duo_bwd_kernel<PD>); }
+
+int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, float* ws, size_t ws_bytes, hipStream_t st,
+                   const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
+    if (pb.kind == NOCF_PROB_QUADCOPTER) return 1;
+    const long chunk = duo_rows_per_launch();
+    DuoPlan dp0;
+    if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(h.n, chunk), &dp0, true) != 0) return 1;
+    if (ws_bytes < duo_ws_bytes_of(dp0)) return 1;
+    const void* fk = pb.kind == NOCF_PROB_CROSS2D ? duo_bwd_fn<2>() : duo_bwd_fn<3>();
+    int dev = 0, cus = 0, perCU = 0;
+    if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) return 1;
+    const size_t ldsBytes0 = (size_t)dp0.ldsFloats * 4;
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024));
+    if (e) return (int)e;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fk, 256, ldsBytes0) != hipSuccess) return 1;
+    const int grid0 = 128 * ((dp0.ngroups + 7) / 8);
+    if ((long)perCU * cus < grid0) {
+        if (debug) fprintf(stderr, "[nocf] duo adjoint kernel: grid %d does not fit (%d workgroups per CU x %d CUs)\n", grid0, perCU, cus);
+        return 1;
+    }
+    DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
+    const int nstage = (h.stepper == NOCF_RK4) ? 4 : 1;
+    for (long r0 = 0; r0 < h.n; r0 += chunk) {
+        const long cn = std::min<long>(chunk, h.n - r0);
+        DuoPlan dp;
+        int rc = make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cn, &dp, true);
+        if (rc) return rc;
+        dp.cb = phi->cb;
+        dp.fast = du_env_int("NOCF_DUO_FAST", 1);
+        dp.mapmode = du_env_int("NOCF_DUO_MAP", 3);
+        dp.dbg = du_env_int("NOCF_DUO_DBG", 0);
+        dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
+        hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws);
+        if (r0 == 0) { e = hipMemsetAsync(ws + dp.oErr, 0, 64 * 4, st); if (e) return (int)e; }
+        e = hipMemsetAsync(ws + dp.oXcc, 0, (32 * 16 + 8 * 520) * 4, st); if (e) return (int)e;
+        e = hipMemsetAsync(ws + dp.oX, 0xFF, (size_t)dp.ngroups * dp.xStride * 4, st);
+        if (e) return (int)e;
+        DuoBwdArgs ba;
+        ba.sAll = h.s_all; ba.zT = h.z_final; ba.hs = h.hs; ba.tape = h.tape; ba.tapeU1 = h.tapeU1; ba.tapeSc = h.tapeSc;
+        ba.R = ((long)h.nt * nstage + 1) * h.n; ba.n = cn; ba.nt = h.nt; ba.nstage = nstage;
+        ba.a0 = h.a0; ba.a3 = h.a3; ba.a4 = h.a4; ba.a5 = h.a5; ba.inv_n = h.inv_n;
+        ba.Y = h.Y; ba.Ab = h.Ab; ba.Wb = h.Wb; ba.Qb = h.Qb; ba.Ob = h.Ob; ba.Gb = h.Gb; ba.lam0 = h.lam0;
+        ba.stamps = h.stamps;
+        DuoRun rr{r0, h.n};
+        const DuoPlan* dpp = reinterpret_cast<const DuoPlan*>(ws + dp.oPlan);
+        const size_t ldsBytes = (size_t)dp.ldsFloats * 4;
+        if (debug) fprintf(stderr, "[nocf] duo adjoint kernel: rows %ld..%ld, %d groups x 16 workgroups, %d tile(s) of 16 samples, LDS %zu B/workgroup, %d workgroups/CU fit\n",
+                           r0, r0 + cn, dp.ngroups, dp.NT, ldsBytes, perCU);
+        void* args[] = {(void*)&dpp, (void*)&pb, (void*)&ws, (void*)&ba, (void*)&rr};
+        if (ev0 && r0 == 0) (void)hipEventRecord(ev0, st);
+        e = hipLaunchKernel(fk, dim3(128 * ((dp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st);
+        if (e) return (int)e;
+        if (ev1 && r0 + chunk >= h.n) (void)hipEventRecord(ev1, st);
     }
     *errp = reinterpret_cast<const unsigned*>(ws) + dp0.oErr;
     return 0;

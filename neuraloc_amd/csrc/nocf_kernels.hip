@@ -1835,7 +1835,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
                         double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
                         float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
                         void* workspace, size_t workspace_bytes, void* stream, float* s_all,
-                        float* act = nullptr, int32_t* act_recorded = nullptr) {
+                        float* act = nullptr, int32_t* act_recorded = nullptr, float* tapeU1 = nullptr, float* tapeSc = nullptr) {
     if (act_recorded) *act_recorded = 0;
     int rc = check_phi(phi);
     if (rc) return rc;
@@ -1862,6 +1862,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     ra.stamps = g_stamp_buf;
     ra.sAll = s_all;
     ra.act = nullptr; ra.actRows = 0;             // (only the split-role kernel records activations: set below)
+    ra.tapeU1 = nullptr; ra.tapeSc = nullptr;
     hipError_t e;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const unsigned* errp = nullptr;
@@ -1904,8 +1905,9 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
         }
         if (act && s_all) { ra.act = act; ra.actRows = (long)nt * ((stepper == NOCF_RK4) ? 4 : 1) * n; }
+        if (act && s_all && tapeSc) { ra.actRows += n; ra.tapeU1 = tapeU1; ra.tapeSc = tapeSc; }       // tape: the terminal block too
         rc = duo_launch(phi, pb, ra, ws, workspace_bytes, st, &errp, env_int("NOCF_DEBUG", 0), g_prof_on ? ev0 : nullptr, g_prof_on ? ev1 : nullptr);
-        ra.act = nullptr; ra.actRows = 0;
+        ra.act = nullptr; ra.actRows = 0; ra.tapeU1 = nullptr; ra.tapeSc = nullptr;
         if (rc == 0) {
             if (act && s_all && act_recorded) *act_recorded = 1;
             g_last_kernel = "rollout_duo_kernel";
@@ -1946,7 +1948,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             (void)hipEventRecord(ev0, st);
         }
         const MonoPlan* mpp = reinterpret_cast<const MonoPlan*>(ws + mpl.pp.oPlan);
-        const bool mono_rec = act && s_all && (phi->m % 16) == 0;              // activation record: the one-CU kernel writes it too
+        const bool mono_rec = act && s_all && !tapeSc && (phi->m % 16) == 0;   // activation record: the one-CU kernel writes it too
         if (mono_rec) { ra.act = act; ra.actRows = (long)nt * ((stepper == NOCF_RK4) ? 4 : 1) * n; }
         void* args[] = {(void*)&mpp, (void*)&pb, (void*)&ws, (void*)&ra};
         e = hipLaunchKernel(fk, dim3((int)((n + 15) / 16)), dim3(256), args, ldsBytes, st); if (e) return (int)e;
@@ -2058,6 +2060,97 @@ static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n,
                             const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
                             float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
                             float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream);
+
+// ---- training tape + split-role adjoint (nocf_duo_bwd.inc)
+static void tape_offsets(int32_t d, int32_t m, int64_t n, int32_t nt, int32_t stepper, size_t* oU1, size_t* oSc, size_t* total) {
+    const size_t R = ((size_t)nt * ((stepper == NOCF_RK4) ? 4 : 1) + 1) * (size_t)n;
+    const size_t gpad = (R * (size_t)(d + 1) + 3) / 4 * 4;
+    *oU1 = 4 * R * (size_t)m + gpad;
+    *oSc = *oU1 + (size_t)n * (size_t)m;
+    *total = *oSc + 4 * R;
+}
+
+size_t nocf_tape_floats(int32_t d, int32_t m, int32_t nTh, int64_t n, int32_t nt, int32_t stepper) {
+#ifdef NOCF_JIT_ONLY
+    (void)d; (void)m; (void)nTh; (void)n; (void)nt; (void)stepper;
+    return 0;
+#else
+    size_t dummy = 0, a, b, tot;
+    if (nTh != 2 || n < 1 || nt < 1 || (stepper != NOCF_RK4 && stepper != NOCF_RK1)) return 0;
+    if (env_int("NOCF_DUO", 1) == 0 || env_int("NOCF_DUO_BWD", 1) == 0) return 0;
+    if (duo_workspace_bytes(d, m, nTh, d + 1 < 10 ? d + 1 : 10, 1, n, &dummy) != 0) return 0;
+    tape_offsets(d, m, n, nt, stepper, &a, &b, &tot);
+    return tot;
+#endif
+}
+
+int nocf_rollout_tape_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                          double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                          float* z_out, float* persample, float* cost_sums, float* s_all, float* tape, int32_t* recorded,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!s_all || !z_out || !phi) return NOCF_E_NULL;
+    if (!tape)
+        return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, nullptr, nullptr,
+                            workspace, workspace_bytes, stream, s_all, nullptr, recorded);
+    size_t oU1, oSc, tot;
+    tape_offsets(phi->d, phi->m, n, nt, stepper, &oU1, &oSc, &tot);
+    return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, nullptr, nullptr,
+                        workspace, workspace_bytes, stream, s_all, tape, recorded, tape + oU1, tape + oSc);
+}
+
+__global__ void poison_kernel(float* __restrict__ buf, long count, const unsigned* __restrict__ errp) {
+    if (*errp == 0u) return;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) buf[i] = __uint_as_float(0x7fc00000u);
+}
+
+int nocf_poison_if_failed_f32(float* buf, int64_t count, void* stream) {
+    if (!buf) return NOCF_E_NULL;
+    if (!g_last_errp || count < 1) return 0;
+    hipLaunchKernelGGL(poison_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, buf, (long)count, g_last_errp);
+    return (int)hipGetLastError();
+}
+
+int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
+                              const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                              const float* tape, float* Y, float* Ab, float* Wb, float* Qb, float* Ob, float* Gb, float* lam0,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+#ifdef NOCF_JIT_ONLY
+    (void)phi; (void)prob; (void)n; (void)nt; (void)stepper; (void)alph; (void)inv_n; (void)s_all; (void)z_final; (void)hs; (void)tape;
+    (void)Y; (void)Ab; (void)Wb; (void)Qb; (void)Ob; (void)Gb; (void)lam0; (void)workspace; (void)workspace_bytes; (void)stream;
+    return NOCF_E_SHAPE;
+#else
+    int rc = check_phi(phi);
+    if (rc) return rc;
+    if (!alph || !s_all || !z_final || !hs || !tape || !Y || !Ab || !Wb || !Qb || !Ob || !Gb || !workspace) return NOCF_E_NULL;
+    if (n < 1 || nt < 1) return NOCF_E_SHAPE;
+    if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
+    DevProb pb;
+    rc = fill_prob(prob, phi->d, &pb);
+    if (rc) return rc;
+    size_t oU1, oSc, tot;
+    tape_offsets(phi->d, phi->m, n, nt, stepper, &oU1, &oSc, &tot);
+    DuoBwdHost h;
+    h.s_all = s_all; h.z_final = z_final; h.hs = hs; h.tape = tape; h.tapeU1 = tape + oU1; h.tapeSc = tape + oSc;
+    h.n = n; h.nt = nt; h.stepper = stepper;
+    h.a0 = alph[0]; h.a3 = alph[3]; h.a4 = alph[4]; h.a5 = alph[5]; h.inv_n = (float)inv_n;
+    h.Y = Y; h.Ab = Ab; h.Wb = Wb; h.Qb = Qb; h.Ob = Ob; h.Gb = Gb; h.lam0 = lam0;
+    h.stamps = g_stamp_buf;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_prof_on) { if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown; }
+    const unsigned* errp = nullptr;
+    g_last_errp = nullptr;
+    rc = duo_bwd_launch(phi, pb, h, (float*)workspace, workspace_bytes, (hipStream_t)stream, &errp, env_int("NOCF_DEBUG", 0), ev0, ev1);
+    if (rc == 0) {
+        g_last_errp = errp;
+        g_last_kernel = "rollout_duo_bwd_kernel";
+        if (g_prof_on) g_prof_events.emplace_back(ev0, ev1);
+        return 0;
+    }
+    if (g_prof_on) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+    return rc == 1 ? NOCF_E_SHAPE : rc;
+#endif
+}
 
 int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
                          const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,

@@ -99,11 +99,39 @@ class _OCflowTrain(torch.autograd.Function):
         persample = torch.empty(n, 7, device=dev)
         sums = torch.empty(8, device=dev)
         z_out = torch.empty(n, d + 4, device=dev)
-        s_all = torch.empty(nt * nstage, n, d + 1, device=dev)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         _lib.check_errors()
+        ctx.tape = None
         with torch.cuda.device(dev):
             L = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+            # Training tape (wide two-layer networks on the split-role kernel): the recording forward keeps what autograd would keep of the
+            # unrolled graph -- u0, tanh(o), tanh(q), a, grad Phi and three scalars of every evaluation, the terminal one included, 2.9 GB for
+            # swarm50 -- and the backward is the split-role adjoint (csrc/nocf_duo_bwd.inc).  NOCF_DUO_BWD=0: the per-tile adjoint below.
+            ntape = int(L.nocf_tape_floats(int(d), int(net.m), int(net.nTh), int(n), int(nt), _STEPPERS[stepper])) \
+                if hasattr(L, "nocf_tape_floats") and os.environ.get("NOCF_ACT_REC", "1") not in ("0", "") else 0
+            tape = None
+            if ntape:
+                try:
+                    tape = torch.empty(ntape, device=dev)
+                except torch.OutOfMemoryError:
+                    tape = None
+            if tape is not None:
+                s_all = torch.empty(nt * nstage + 1, n, d + 1, device=dev)
+                recorded = C.c_int32(0)
+                rc = L.nocf_rollout_tape_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+                                             float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
+                                             _lib.ptr(z_out), _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(s_all),
+                                             _lib.ptr(tape), C.byref(recorded),
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                _lib.check(rc, "nocf_rollout_tape_f32")
+                if recorded.value:
+                    ctx.tape = tape
+                else:                                             # another kernel ran (problem class, residency): plain stage inputs
+                    s_all = s_all[:nt * nstage]
+        if tape is not None:
+            return _OCflowTrain._forward_tail(ctx, L, dev, net, prob, tspan, nt, stepper, alph, n_total, group, n, sums, s_all, z_out)
+        s_all = torch.empty(nt * nstage, n, d + 1, device=dev)
+        with torch.cuda.device(dev):
             # activation record (wide two-layer networks on the split-role kernel): the forward keeps u0, tanh(o), tanh(q), a and grad Phi
             # of every evaluation -- autograd's saved tensors, 2.9 GB for swarm50 -- and the adjoint loads them instead of re-running
             # grad Phi's forward sweep (NOCF_ACT_REC=0: recompute, as for every other shape)
@@ -124,6 +152,10 @@ class _OCflowTrain(torch.autograd.Function):
                                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_record_act_f32")
         ctx.act = act if recorded.value else None
+        return _OCflowTrain._forward_tail(ctx, L, dev, net, prob, tspan, nt, stepper, alph, n_total, group, n, sums, s_all, z_out)
+
+    @staticmethod
+    def _forward_tail(ctx, L, dev, net, prob, tspan, nt, stepper, alph, n_total, group, n, sums, s_all, z_out):
         _lib.track_rollout_status(L, dev, "OCflow (training forward)")
         ctx.net, ctx.prob, ctx.tspan, ctx.nt, ctx.stepper, ctx.alph = net, prob, tspan, nt, stepper, list(alph)
         ctx.group = group
@@ -151,7 +183,12 @@ class _OCflowTrain(torch.autograd.Function):
         dev = s_all.device
         n, d = z_out.shape[0], z_out.shape[1] - 4
         m, D1 = net.m, d + 1
-        nstage = s_all.shape[0] // nt
+        nstage = 4 if ctx.stepper == "rk4" else 1
+        if getattr(ctx, "tape", None) is not None:
+            out = _OCflowTrain._backward_tape(ctx, gJ, s_all, z_out, n, d, m, D1, nstage)
+            if out is not None:
+                return out
+            s_all = s_all[:nt * nstage]                            # (the split-role adjoint did not qualify after all: per-tile adjoint)
         rows = (nt * nstage + 2) * n
         phi_st, keep1, ws = net._c_struct(n)
         prob_st, keep2 = prob._c_struct(dev)
@@ -216,6 +253,51 @@ class _OCflowTrain(torch.autograd.Function):
         grads["c.bias"] = PHIb.sum().reshape(1)
         dM = _contract(Gb, Sx) + 0.5 * (sT * PHIb[:, None]).t() @ sT
         grads["A"] = net.A.detach() @ (dM + dM.t())
+        return _OCflowTrain._finish(ctx, gJ, grads, lam0, net)
+
+    @staticmethod
+    def _backward_tape(ctx, gJ, s_all, z_out, n, d, m, D1, nstage):
+        """the split-role adjoint on the forward's tape (include/nocf.h: nocf_rollout_bwd_tape_f32); None when it does not qualify"""
+        net, prob, nt, alph, tape = ctx.net, ctx.prob, ctx.nt, ctx.alph, ctx.tape
+        dev = s_all.device
+        E = nt * nstage + 1
+        R = E * n
+        phi_st, keep1, ws = net._c_struct(n)
+        prob_st, keep2 = prob._c_struct(dev)
+        hs = _step_sizes(ctx.tspan, nt).to(dev)
+        alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+        lam0 = torch.empty(n, d, device=dev) if ctx.x_needs_grad else None
+        Y, Ab, Wb, Qb, Ob = (torch.empty(R, m, device=dev) for _ in range(5))
+        Gb = torch.empty(R, D1, device=dev)
+        lib = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+        with torch.cuda.device(dev):
+            rc = lib.nocf_rollout_bwd_tape_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper], alph_c,
+                                               1.0 / float(ctx.n_total), _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(tape),
+                                               _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Wb), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb),
+                                               _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        if rc == -2:
+            return None
+        _lib.check(rc, "nocf_rollout_bwd_tape_f32")
+        _lib.track_rollout_status(lib, dev, "OCflow (backward)")
+        U0, TH1 = tape[:R * m].view(R, m), tape[2 * R * m:3 * R * m].view(R, m)
+        gpad = (R * D1 + 3) // 4 * 4
+        sc = tape[4 * R * m + gpad + n * m:].view(R, 4)
+        Sx = s_all.view(R, D1)
+        sT = Sx[R - n:]
+        phib = torch.sign(sc[R - n:, 0]) * (float(alph[4]) / float(ctx.n_total))      # cotangent of Phi(z(T), T) (HJfin, src/OCflow.py:70-76)
+        w = net.w.weight.detach().reshape(-1, 1)
+        grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": _colsum(Ob),
+                 "N.layers.1.weight": _contract(Qb, U0, w * _contract(TH1, Ab)), "N.layers.1.bias": _colsum(Qb),
+                 "w.weight": _colsum(Wb).reshape(1, -1),
+                 "c.weight": (_colsum(Gb) + phib @ sT).reshape(1, -1), "c.bias": phib.sum().reshape(1)}
+        dM = _contract(Gb, Sx) + 0.5 * (sT * phib[:, None]).t() @ sT
+        grads["A"] = net.A.detach() @ (dM + dM.t())
+        ctx.tape = None
+        # a timed-out exchange leaves garbage rows: turn every gradient into NaN on the stream (the host raises at its next check)
+        flat = [grads[name] for name, _ in net.named_parameters()]
+        with torch.cuda.device(dev):
+            for g_ in flat + ([lam0] if lam0 is not None else []):
+                lib.nocf_poison_if_failed_f32(_lib.ptr(g_), g_.numel(), _lib.stream_ptr(dev))
         return _OCflowTrain._finish(ctx, gJ, grads, lam0, net)
 
     @staticmethod

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Debug aid for the split-role adjoint (csrc/nocf_duo_bwd.inc): runs the tape forward + the new adjoint and the record forward + the
+per-tile adjoint on the same swarm50 batch through the C ABI and compares, block by block, the tape with the record, every row
+stream, lam0 and finally the parameter gradients.  usage: python tools/dbg_duo_bwd.py [n] [nt] [stepper] [train|eval]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+os.environ.setdefault("NOCF_ENV_WATCH", "1")
+import neuraloc_amd as na                                   # noqa: E402
+from neuraloc_amd import _lib                                # noqa: E402
+from neuraloc_amd.train import _step_sizes                   # noqa: E402
+from bench import load_workload, make_states                # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    nt = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    stepper = sys.argv[3] if len(sys.argv) > 3 else "rk4"
+    training = (sys.argv[4] if len(sys.argv) > 4 else "train") == "train"
+    dev = torch.device("cuda:0")
+    meta, sd, xtarget, xInit = load_workload("swarm50")
+    alph = list(meta["alph"])
+    alph[3], alph[4], alph[5] = 2.0, 3.0, 1.5               # (the checkpoint's are 0: exercise the HJ terms too)
+    net = na.Phi(nTh=2, m=meta["m"], d=meta["d"], alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    prob = na.SwarmTraj(xtarget.to(dev), obstacle=meta["obstacle"], alph_Q=meta["alph_Q"], alph_W=meta["alph_W"], r=meta["r"])
+    prob.train() if training else prob.eval()
+    x = make_states(meta, xInit, max(n, 8), seed=200)[:n].contiguous().to(dev)
+    if len(sys.argv) > 5:                                    # squeeze the swarm so that agents interact
+        x = (x * float(sys.argv[5])).contiguous()
+    d, m = meta["d"], meta["m"]
+    D1 = d + 1
+    nstage = 4 if stepper == "rk4" else 1
+    total = nt * nstage
+    E = total + 1
+    R = E * n
+    st = _lib.NOCF_RK4 if stepper == "rk4" else _lib.NOCF_RK1
+    L = _lib.lib()
+    phi_st, keep1, ws = net._c_struct(n)
+    prob_st, keep2 = prob._c_struct(dev)
+    alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+    sp = _lib.stream_ptr(dev)
+    hs = _step_sizes([0.0, 1.0], nt).to(dev)
+
+    def fwd(tape_mode):
+        ps, sums, z = torch.empty(n, 7, device=dev), torch.empty(8, device=dev), torch.empty(n, d + 4, device=dev)
+        rec = C.c_int32(0)
+        if tape_mode:
+            nf = int(L.nocf_tape_floats(d, m, 2, n, nt, st))
+            assert nf > 0, "no tape for this shape"
+            tape = torch.full((nf,), float("nan"), device=dev)
+            s_all = torch.full((E, n, D1), float("nan"), device=dev)
+            rc = L.nocf_rollout_tape_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n, 0.0, 1.0, nt, st, alph_c, _lib.ptr(z), _lib.ptr(ps),
+                                         _lib.ptr(sums), _lib.ptr(s_all), _lib.ptr(tape), C.byref(rec), _lib.ptr(ws), ws.numel(), sp)
+        else:
+            nf = int(L.nocf_activation_record_floats(d, m, 2, n, nt, st))
+            tape = torch.full((nf,), float("nan"), device=dev)
+            s_all = torch.full((total, n, D1), float("nan"), device=dev)
+            rc = L.nocf_rollout_record_act_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n, 0.0, 1.0, nt, st, alph_c, _lib.ptr(z), _lib.ptr(ps),
+                                               _lib.ptr(sums), _lib.ptr(s_all), _lib.ptr(tape), C.byref(rec), _lib.ptr(ws), ws.numel(), sp)
+        _lib.check(rc, "forward")
+        torch.cuda.synchronize()
+        print(f"forward tape={tape_mode}: kernel {L.nocf_last_rollout_kernel().decode()} recorded={rec.value} sums={sums.cpu().numpy()}")
+        return tape, s_all, z, ps
+
+    tape, s_all, z, ps = fwd(True)
+    act, s_old, z_old, ps_old = fwd(False)
+    print("z_out equal:", torch.equal(z, z_old), " persample equal:", torch.equal(ps, ps_old))
+    print("s_all blocks < total equal:", torch.equal(s_all[:total], s_old), " terminal s block finite:", bool(torch.isfinite(s_all[total]).all()),
+          " = [z(T), 1]:", torch.equal(s_all[total, :, :d], z[:, :d]), float(s_all[total, 0, d]))
+    for sec, name in enumerate(["u0", "tanh(o)", "tanh(q)", "a"]):
+        new = tape[sec * R * m:(sec + 1) * R * m].view(E, n, m)
+        old = act[sec * total * n * m:(sec + 1) * total * n * m].view(total, n, m)
+        print(f"tape {name}: blocks < total equal {torch.equal(new[:total], old)}; terminal finite {bool(torch.isfinite(new[total]).all())}")
+    gnew = tape[4 * R * m:4 * R * m + R * D1].view(E, n, D1)
+    gold = act[4 * total * n * m:].view(total, n, D1)
+    print("tape grad Phi: blocks < total equal", torch.equal(gnew[:total], gold), " terminal finite", bool(torch.isfinite(gnew[total]).all()))
+    gpad = (R * D1 + 3) // 4 * 4
+    u1 = tape[4 * R * m + gpad:4 * R * m + gpad + n * m].view(n, m)
+    sc = tape[4 * R * m + gpad + n * m:].view(E, n, 4)
+    print("tape u1 finite", bool(torch.isfinite(u1).all()), " scalars finite", bool(torch.isfinite(sc).all()), " sc[0,0]", sc[0, 0].cpu().numpy(), " sc[T,0]", sc[total, 0].cpu().numpy())
+    print("active (q or w != 0) rows:", int(((sc[:total, :, 1] != 0) | (sc[:total, :, 2] != 0)).sum()), "of", total * n)
+
+    inv_n = 1.0 / n
+    # new adjoint
+    Y, Ab, Wb, Qb, Ob = (torch.full((R, m), float("nan"), device=dev) for _ in range(5))
+    Gb = torch.full((R, D1), float("nan"), device=dev)
+    lam0 = torch.full((n, d), float("nan"), device=dev)
+    rc = L.nocf_rollout_bwd_tape_f32(C.byref(phi_st), C.byref(prob_st), n, nt, st, alph_c, inv_n, _lib.ptr(s_all), _lib.ptr(z), _lib.ptr(hs), _lib.ptr(tape),
+                                     _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Wb), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), sp)
+    print("nocf_rollout_bwd_tape_f32 rc", rc)
+    _lib.check(rc, "bwd tape")
+    torch.cuda.synchronize()
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    L.nocf_last_rollout_status_async(C.c_void_p(word.data_ptr()), sp)
+    torch.cuda.synchronize()
+    print("adjoint kernel:", L.nocf_last_rollout_kernel().decode(), " error word 0x%x" % int(word[0]))
+    # old adjoint
+    rows = (total + 2) * n
+    oY, oOb, oWb = (torch.zeros(rows, m, device=dev) for _ in range(3))
+    oV, oAb, oQb, oU0 = (torch.zeros(1, rows, m, device=dev) for _ in range(4))
+    oGb, oSx = torch.zeros(rows, D1, device=dev), torch.zeros(rows, D1, device=dev)
+    oPHI = torch.zeros(n, device=dev)
+    olam = torch.zeros(n, d, device=dev)
+    rc = L.nocf_rollout_bwd_act_f32(C.byref(phi_st), C.byref(prob_st), n, nt, st, 1.0, alph_c, inv_n, _lib.ptr(s_old), _lib.ptr(z_old), _lib.ptr(hs),
+                                    _lib.ptr(oY), _lib.ptr(oOb), _lib.ptr(oV), _lib.ptr(oAb), _lib.ptr(oQb), _lib.ptr(oU0), _lib.ptr(oWb), _lib.ptr(oGb),
+                                    _lib.ptr(oSx), _lib.ptr(oPHI), _lib.ptr(olam), _lib.ptr(act), _lib.ptr(ws), ws.numel(), sp)
+    _lib.check(rc, "bwd old")
+    torch.cuda.synchronize()
+
+    def cmp(name, new, old, blocks):
+        new, old = new.view(E, n, -1), old
+        worst = (0.0, -1)
+        nan_blocks = []
+        for b in blocks:
+            dlt = (new[b] - old[b]).abs()
+            if not torch.isfinite(new[b]).all():
+                nan_blocks.append(b)
+                continue
+            sc_ = float(old[b].abs().max()) + 1e-30
+            r_ = float(dlt.max()) / sc_
+            if r_ > worst[0]:
+                worst = (r_, b)
+        print(f"  {name:4s}: worst rel diff {worst[0]:.3e} at block {worst[1]}" + (f"; NON-FINITE blocks {nan_blocks[:8]}{'...' if len(nan_blocks) > 8 else ''}" if nan_blocks else ""))
+
+    blocks = list(range(total, -1, -1))
+    print("row streams, new vs per-tile adjoint (blocks total .. 0; the terminal block of qbar / obar / dw carries the value rows):")
+    oview = lambda t_: t_.view(total + 2, n, -1)
+    cmp("Gb", Gb, oview(oGb), blocks)
+    cmp("Ab", Ab, oview(oAb[0]), blocks)
+    cmp("Y", Y, oview(oY), blocks)
+    oq = oview(oQb[0]).clone(); oq[total] += oq[total + 1]
+    oo = oview(oOb).clone(); oo[total] += oo[total + 1]
+    ow = oview(oWb).clone(); ow[total] += ow[total + 1]
+    cmp("Qb", Qb, oq, blocks)
+    cmp("Ob", Ob, oo, blocks)
+    cmp("Wb", Wb, ow, blocks)
+    dl = (lam0 - olam).abs().max().item() / (olam.abs().max().item() + 1e-30)
+    print(f"  lam0: rel diff {dl:.3e} (scale {olam.abs().max().item():.3e}); finite {bool(torch.isfinite(lam0).all())}")
+
+    # whole training step through the package: new vs per-tile adjoint vs recompute
+    grads = {}
+    for tag, env in (("tape", {}), ("tile+record", {"NOCF_DUO_BWD": "0"}), ("tile recompute", {"NOCF_ACT_REC": "0"})):
+        for k in ("NOCF_DUO_BWD", "NOCF_ACT_REC"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        net.zero_grad()
+        net.train()
+        Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, stepper, alph)
+        Jc.backward()
+        torch.cuda.synchronize()
+        grads[tag] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        print(f"{tag}: Jc = {Jc.item():.9e}")
+    for k in ("NOCF_DUO_BWD", "NOCF_ACT_REC"):
+        os.environ.pop(k, None)
+    for k in grads["tape"]:
+        a, b, c = grads["tape"][k], grads["tile+record"][k], grads["tile recompute"][k]
+        s_ = c.abs().max().item() + 1e-30
+        print(f"  grad {k:20s} scale {s_:.3e}  tape vs tile+record {(a - b).abs().max().item() / s_:.3e}  tape vs recompute {(a - c).abs().max().item() / s_:.3e}"
+              f"  (record vs recompute {(b - c).abs().max().item() / s_:.3e})")
+    _lib.check_errors(sync=True)
+
+
+if __name__ == "__main__":
+    main()
