@@ -223,10 +223,10 @@ int nocf_rollout_bwd_act_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
  *   *recorded = 1 when the launched kernel wrote the tape (else only the first nt*nstage blocks of s_all are written: fall back to
  *   nocf_rollout_bwd_f32).
  * nocf_rollout_bwd_tape_f32: the adjoint of the discrete scheme on the split-role layout.  Writes the row vectors whose outer products
- *   are the weight gradients, one row per (block, sample) as on the tape (the value's rows of nocf_rollout_bwd_f32 are folded into the
- *   terminal block):
+ *   are the weight gradients, one row per (block, sample) as on the tape:
  *     Y = tanh(o).a, Ab = abar0, Wb = dw row, Qb = qbar, Ob = obar   device [R, m];   Gb = gbar   device [R, d+1]
- *   so that, with the tape's U0 = u0, TH1 = tanh(q) and Sx = s_all,
+ *   The value's rows of nocf_rollout_bwd_f32 (cotangent phib of Phi(z(T), T)) are NOT in them: the caller adds phib.tanh(q).w to Qb,
+ *   phib.Y to Ob and phib.u_1 (tape) to Wb on the n rows of the terminal block.  Then, with the tape's U0 = u0, TH1 = tanh(q), Sx = s_all,
  *     dK0 = Y'Gb + Ob'Sx,  db0 = colsum Ob,  dK1 = diag(w) TH1'Ab + Qb'U0,  db1 = colsum Qb,  dw = colsum Wb,
  *     dc.weight = colsum Gb + phib'sT,  d(A'A) = Gb'Sx + (sT.phib)'sT / 2,  phib = alph4 sign(tape scalar of the terminal block) / n_total.
  *   lam0 device [n, d] = dJc/dx0 (nullable).  Returns NOCF_E_SHAPE when the shape / problem / residency does not qualify (nothing launched).

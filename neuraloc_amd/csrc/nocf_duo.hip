@@ -1176,7 +1176,8 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
     dp.NT = (int)((ntiles + dp.ngroups - 1) / dp.ngroups);
     if (dp.NT > DU_NTMAX) return NOCF_E_SHAPE;
     dp.hN = 1.0f;
-    const int ldsA = DA_T + 2 * dp.NT * (bwd ? DSB_STRIDE : DS_STRIDE), ldsB = DB_END;
+    if (bwd && r > 10) return NOCF_E_SHAPE;                                        // (the adjoint keeps 10 rows of A in LDS)
+    const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE : DA_T + 2 * dp.NT * DS_STRIDE, ldsB = DB_END;
     dp.ldsFloats = std::max(ldsA, ldsB);
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
     long o = 0;                                                                    // floats

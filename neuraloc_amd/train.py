@@ -286,6 +286,12 @@ class _OCflowTrain(torch.autograd.Function):
         sT = Sx[R - n:]
         phib = torch.sign(sc[R - n:, 0]) * (float(alph[4]) / float(ctx.n_total))      # cotangent of Phi(z(T), T) (HJfin, src/OCflow.py:70-76)
         w = net.w.weight.detach().reshape(-1, 1)
+        # the value's rows (weight gradients only: the state's share of this cotangent is already in the terminal lambda) ride on the
+        # terminal block: qbar += phib v, obar += phib y, dw row += phib u_1
+        u1 = tape[4 * R * m + gpad:4 * R * m + gpad + n * m].view(n, m)
+        Qb[R - n:].addcmul_(TH1[R - n:] * w.t(), phib[:, None])
+        Ob[R - n:].addcmul_(Y[R - n:], phib[:, None])
+        Wb[R - n:].addcmul_(u1, phib[:, None])
         grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": _colsum(Ob),
                  "N.layers.1.weight": _contract(Qb, U0, w * _contract(TH1, Ab)), "N.layers.1.bias": _colsum(Qb),
                  "w.weight": _colsum(Wb).reshape(1, -1),

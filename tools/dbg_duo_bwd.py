@@ -102,6 +102,11 @@ def main():
     L.nocf_last_rollout_status_async(C.c_void_p(word.data_ptr()), sp)
     torch.cuda.synchronize()
     print("adjoint kernel:", L.nocf_last_rollout_kernel().decode(), " error word 0x%x" % int(word[0]))
+    phib = torch.sign(sc[total, :, 0]) * (float(alph[4]) / n)               # the value's rows (the caller's part: include/nocf.h)
+    wv = net.w.weight.detach().reshape(1, -1)
+    Qb[R - n:] += phib[:, None] * (tape[2 * R * m:3 * R * m].view(R, m)[R - n:] * wv)
+    Ob[R - n:] += phib[:, None] * Y[R - n:]
+    Wb[R - n:] += phib[:, None] * u1
     # old adjoint
     rows = (total + 2) * n
     oY, oOb, oWb = (torch.zeros(rows, m, device=dev) for _ in range(3))
