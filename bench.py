@@ -133,12 +133,36 @@ def cpu_baseline(meta, sd, xtarget, x, nt, budget_s=60.0):
     head = max(traj, key=traj.get)
     table = ", ".join(f"{k}t:{n / nt / v:.0f}" for k, v in step_s.items())
     legtxt = "; ".join(f"{th} thread(s): {v[1]} step(s)/call, {v[2]}" for th, v in legs.items())
-    return {"value": traj[head], "unit": "trajectories/s", "cores": head, "kind": "port",
+    # ... and ONE full nt-step rollout at the headline thread count validates the extrapolation inside this run (SURVEY 8(d) times full
+    # rollouts): skipped only when it would take longer than the remaining budget allows
+    full_s, value, basis = None, traj[head], "extrapolated from the sampled steps"
+    est_full = legs[head][0] * nt
+    if est_full <= max(10.0, budget_s / 2.0):
+        torch.set_num_threads(head)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            orc.rollout(x, P, S, [0.0, 1.0], nt, "rk4", meta["alph"])
+            full_s = time.perf_counter() - t0
+        if abs(full_s - est_full) > 0.10 * est_full:     # disagreement: the measured full rollout is the figure
+            value, basis = n / full_s, "one full rollout (the sampled-step extrapolation was off by more than 10 %)"
+    return {"value": value, "unit": "trajectories/s", "cores": head, "kind": "port", "value_basis": basis,
+            "extrapolated_traj_per_s": traj[head], "full_rollout_s": full_s, "full_rollout_traj_per_s": (n / full_s) if full_s else None,
+            "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
             "one_thread": traj[1], "all_cores": traj[ncpu], "all_cores_count": ncpu, "best_probe": traj[best], "best_probe_threads": best,
             "sample": f"n={n} rows, the first steps of the {nt}-step RK4 rollout at the same h, scaled to {nt} steps; {legtxt}; "
                       f"thread probe (1 step, traj/s-equivalent): {table}" + ("; " + "; ".join(notes) if notes else "")
                       + f"; eager PyTorch {torch.__version__}",
             "seconds_per_step": legs[head][0]}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def read_traffic(workload, kernel, n_local):
@@ -231,6 +255,68 @@ def quick_measure(name, dev, steps=10, warmup=3):
             "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of": "fp32 MFMA / vector peak 157.3 TFLOP/s (the small networks are latency-bound VALU work: SURVEY 8d)"}
 
 
+def train_measure(name, dev, reps=5):
+    """One training iteration of trainOC.py:170-174 (zero_grad, Jc = OCflow(...), Jc.backward(), Adam step) at the workload's full size,
+    prob.train(): wall time per iteration, the two rollout kernels' own times (HIP events recorded by the library around the recording
+    forward and around the adjoint) and the fraction of the fp32 MFMA roof: an iteration is 3 x the forward's algorithmic FLOPs (forward,
+    vector-Jacobian product of grad Phi, weight-gradient outer products)."""
+    L = _lib.lib()
+    meta, sd, xtarget, xInit = load_workload(name)
+    net, prob = build_objects(meta, sd, xtarget, dev)
+    net.train(); prob.train()
+    n, nt, alph = meta["n_full"], meta["nt"], meta["alph"]
+    x = make_states(meta, xInit, n, seed=200).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+
+    def window(fn):
+        L.nocf_profile_begin()
+        r = fn()
+        kms, nl = C.c_double(0.0), C.c_int32(0)
+        L.nocf_profile_end(C.byref(kms), C.byref(nl))
+        return r, kms.value, L.nocf_last_rollout_kernel().decode()
+
+    for _ in range(2):
+        opt.zero_grad()
+        Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph)
+        Jc.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    fwd_ms = bwd_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        opt.zero_grad()
+        (Jc, _), ms, fk = window(lambda: na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph))
+        fwd_ms += ms
+        _, ms, bk = window(lambda: Jc.backward())
+        bwd_ms += ms
+        opt.step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    na.check_errors(sync=True)
+    fl = 3.0 * flops_per_state_step(meta) * n * nt
+    return {"workload": f"train {name} d={meta['d']} m={meta['m']} nt={nt} n={n} (Adam step, prob.train())", "train_iter_ms": 1e3 * el,
+            "trained_traj_per_s": n / el, "forward_kernel": fk, "forward_kernel_ms": fwd_ms / reps,
+            "adjoint_kernel": bk, "adjoint_kernel_ms": bwd_ms / reps, "flops_per_iteration": fl,
+            "frac": fl / el / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "frac_of": "3 x SURVEY 8(d) forward FLOPs per iteration over the WHOLE iteration's wall time, of the fp32 MFMA peak", "Jc": float(Jc)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a child process (this parent has not
+    touched the GPU: nothing here calls into HIP before this point), relay their output, leave with their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,9 +328,11 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="batch rows: the GLOBAL batch (strong) or rows per GPU (weak); default: BASELINE.json's n")
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of the other four BASELINE configs and the shock sweep")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of the other four BASELINE configs, the shock sweep and the training iterations")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -261,7 +349,7 @@ def main():
             dist.init_process_group(backend=backend)
     else:
         dist = None
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus N` (it starts its own ranks) or torch.distributed.run with N ranks"
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -327,7 +415,9 @@ def main():
         traffic, traffic_src = read_traffic(args.workload, kernel, n_local)
         out = {
             "metric": "trajectories/sec (n_train x nt states integrated)", "value": value, "unit": "trajectories/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "ranks": (dist.get_world_size() if dist else 1),
+            "backend": (os.environ.get("NOCF_BENCH_BACKEND", "nccl") + (" (RCCL)" if os.environ.get("NOCF_BENCH_BACKEND", "nccl") == "nccl" else "")) if dist else "none (single process)",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic states (xInit + var0 * closed-form normal table); pretrained reference weights exported to npz",
             "config": {"workload": f"{args.workload} d={meta['d']} m={meta['m']} nTh={meta['nTh']} nt={nt} "
@@ -350,6 +440,11 @@ def main():
                     others.append(quick_measure(name, dev))
                 except Exception as ex:                          # the headline line must survive a failure here
                     others.append({"workload": name, "error": repr(ex)[:200]})
+            for name in ("swarm50", "singlequad"):               # training: the reference's main use (trainOC.py:160-176)
+                try:
+                    others.append(train_measure(name, dev))
+                except Exception as ex:
+                    others.append({"workload": "train " + name, "error": repr(ex)[:200]})
             out["config"]["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(meta, sd, xtarget, x_cpu, nt)

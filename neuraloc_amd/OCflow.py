@@ -100,6 +100,8 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
                                          _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "nocf_rollout_f32")
     _lib.track_rollout_status(L, dev, "OCflow")
+    if _lib.duo_guard(L, "OCflow"):
+        return _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates)
     return persample, sums, zFull, ctrlFull
 
 
@@ -148,6 +150,9 @@ def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0
         raise NotImplementedError("OCflow in double precision is evaluation only (the adjoint kernels are fp32): call it under "
                                   "torch.no_grad(); train in single precision (trainOC.py's default)")
     persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates and not noMean)
+    if noMean or intermediates:
+        # results that are consumed on the host (plots, files): a timed-out exchange must raise HERE, not at the next call
+        _lib.check_errors(sync=True)
     if noMean:
         cs = [persample[:, i:i + 1] for i in range(7)]
         Jc = cs[0] + alph[0] * cs[1] + alph[3] * cs[2] + alph[4] * cs[3] + alph[5] * cs[4]

@@ -107,14 +107,32 @@ def _jit_fresh(key):
         return None
 
 
+def _profiler_attached():
+    """a profiler / tool library is preloaded into this process (rocprofv3 --pmc and friends): its library would initialise the GPU
+    inside every child process too, and a chain of execs of GPU-initialised processes (sh -> hipcc -> clang -> lld) is what must never
+    happen on a shared pool"""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return any(t in pre for t in ("rocprof", "roctracer", "rocprofiler")) or any(
+        os.environ.get(k) for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+
+
+def _compiler_env():
+    """the environment the compiler child gets: this process's, without anything that preloads a tool library or steers a profiler"""
+    return {k: v for k, v in os.environ.items()
+            if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") and not k.startswith(("ROCP_", "ROCPROFILER_", "ROCTRACER_", "ROCPROF_"))}
+
+
 def _jit_start_background(key):
-    """one compilation at a time per cache directory (lock file), detached child, atomic rename on success; never raises"""
+    """one compilation at a time per cache directory (lock file), detached child with a scrubbed environment, atomic rename on success;
+    never raises; does nothing under a profiler"""
     import subprocess
     import sys
     import time
     if key in _jit_started:
         return False
     _jit_started.add(key)
+    if _profiler_attached():
+        return False
     try:
         _, out_dir, so, _, _, _ = _jit_paths(key)
         os.makedirs(out_dir, exist_ok=True)
@@ -143,7 +161,7 @@ def _jit_start_background(key):
         sh = "%s > %s 2>&1 && mv -f %s %s; rm -f %s %s" % (" ".join(shlex.quote(c) for c in cmd), shlex.quote(so + ".log"),
                                                            shlex.quote(tmp), shlex.quote(so), shlex.quote(tmp), shlex.quote(lock))
         subprocess.Popen(["/bin/sh", "-c", sh], stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                         start_new_session=True)
+                         start_new_session=True, env=_compiler_env())
         print("[neuraloc_amd] shape d=%d m=%d nTh=%d r=%d agents=%d has no specialised kernels in the shipped library: compiling them in the "
               "background (about a minute, cached under csrc/jit/; this process keeps the generic instantiation, NOCF_JIT=1 waits for "
               "the compiler instead, NOCF_JIT=0 switches this off)" % key, file=sys.stderr, flush=True)
@@ -182,7 +200,10 @@ def lib_for(d, m, nTh, r, n_agents):
             raise RuntimeError("NOCF_JIT=1 but hipcc was not found (set HIPCC)")
         print("[neuraloc_amd] NOCF_JIT=1: specialising the kernels for shape d=%d m=%d nTh=%d r=%d agents=%d (about a minute, once)" % key,
               file=sys.stderr, flush=True)
-        subprocess.check_call(cmd)
+        if _profiler_attached():
+            raise RuntimeError("NOCF_JIT=1 under a profiler: compile the shape's library first (run once without the profiler), "
+                               "or set NOCF_JIT=0")
+        subprocess.check_call(cmd, env=_compiler_env())
         os.replace(tmp, so)                       # atomic: ranks that compile the same shape at once do not clash
     if so is None:                                # auto, nothing cached yet
         _jit_start_background(key)
@@ -334,7 +355,39 @@ def check_errors(sync=False):
             raise RuntimeError(f"{what}: the weight-stationary rollout kernel timed out waiting for another workgroup (error word "
                                f"0x{code:x}); its outputs are NaN.  The kernel needs the whole GPU: all of its workgroups must be resident at "
                                "once, so nothing else may run on the device while it does (another stream or process took compute units), "
-                               "or set NOCF_DUO=0 to use the per-tile kernel")
+                               "or set NOCF_DUO=0 in the environment BEFORE the first rollout of the process to use the per-tile kernel "
+                               "(the library reads its knobs once)")
+
+
+# ---- probation of the weight-stationary kernels.  They need every one of their workgroups resident at once; on a GPU that this
+# process shares (a second rank or another job on the same device) their exchange times out.  A timed-out rollout is normally reported
+# asynchronously (above), i.e. after its NaN results have been handed out.  So the first launches of such a kernel in a process are checked
+# SYNCHRONOUSLY: if one timed out, the split-role kernels are switched off for the rest of the process (NOCF_DUO=0, the per-tile kernels
+# need no co-residency) and the caller repeats the call -- a fresh launch in this process, nothing is re-executed.  After the probation
+# (a device that is ours) a later timeout raises as before.
+_duo_probation = {"left": int(os.environ.get("NOCF_DUO_PROBATION", "3"))}
+
+
+def duo_guard(L, what):
+    """call right behind track_rollout_status; True: the launch timed out during probation, the split-role kernels are now off, repeat the call"""
+    if _duo_probation["left"] <= 0 or not L.nocf_last_rollout_kernel().decode().startswith("rollout_duo"):
+        return False
+    _duo_probation["left"] -= 1
+    try:
+        check_errors(sync=True)
+        return False
+    except RuntimeError as ex:
+        if os.environ.get("NOCF_DUO_FALLBACK", "1") in ("0", ""):
+            raise
+        import sys
+        print(f"[neuraloc_amd] {what}: {str(ex).split(';')[0]}; the GPU seems to be shared -- switching this process to the per-tile kernels "
+              "(NOCF_DUO=0) and repeating the call", file=sys.stderr, flush=True)
+        os.environ["NOCF_DUO"] = "0"
+        for lib_ in [_lib] + list(_jit_libs.values()):
+            if lib_ is not None:
+                lib_.nocf_debug_reload_env()
+        _duo_probation["left"] = 0
+        return True
 
 
 def check(rc, what):

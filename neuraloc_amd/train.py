@@ -77,6 +77,13 @@ def _colsum(X):
 class _OCflowTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
+        out = _OCflowTrain._forward_once(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group)
+        if out is None:                                  # (a timed-out launch during the split-role kernels' probation: _lib.duo_guard)
+            out = _OCflowTrain._forward_once(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group)
+        return out
+
+    @staticmethod
+    def _forward_once(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group):
         ctx.x_needs_grad = bool(x.requires_grad)
         x = _lib.require_device_f32(x.detach(), "x")
         # the kernels index with Phi's d: a mismatching x would read and write out of bounds (same checks as OCflow._launch)
@@ -157,6 +164,8 @@ class _OCflowTrain(torch.autograd.Function):
     @staticmethod
     def _forward_tail(ctx, L, dev, net, prob, tspan, nt, stepper, alph, n_total, group, n, sums, s_all, z_out):
         _lib.track_rollout_status(L, dev, "OCflow (training forward)")
+        if _lib.duo_guard(L, "OCflow (training forward)"):
+            return None
         ctx.net, ctx.prob, ctx.tspan, ctx.nt, ctx.stepper, ctx.alph = net, prob, tspan, nt, stepper, list(alph)
         ctx.group = group
         if group is not None:

@@ -13,6 +13,9 @@ if REPO not in sys.path:
 os.environ["NOCF_ENV_WATCH"] = "1"
 # unlisted shapes: no background compilations from the test-suite (the JIT tests switch it on themselves)
 os.environ.setdefault("NOCF_JIT", "0")
+# the synchronous check of a process's first split-role launches (neuraloc_amd._lib.duo_guard) would turn the forced-timeout tests into
+# fallbacks: off in the suite, tested in a child process (tests/test_duo_gpu.py)
+os.environ.setdefault("NOCF_DUO_PROBATION", "0")
 
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 PRETRAINED = ["swap2", "softcorridor", "swap12", "swarm50", "singlequad"]

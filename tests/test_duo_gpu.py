@@ -3,6 +3,8 @@
 against the per-tile kernel (NOCF_DUO=0) on the same inputs.
 
 Tolerances as in test_hip_parity.py: per-sample costs rel 1e-3 + abs 1e-3 (mask flips counted), means rel 1e-4."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,8 @@ from neuraloc_amd import _lib
 from oracle import ocflow_oracle as orc
 from conftest import load_golden
 from util_hip import closed_form_normal, count_off, make_net, make_oracle, make_prob, synth_state_dict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -162,8 +166,9 @@ def test_duo_several_tiles_on_other_problems_against_the_tile_kernel(name, train
 
 
 def test_a_timed_out_exchange_raises_and_poisons_the_outputs(monkeypatch):
-    """NOCF_DUO_SPIN_MAX=1 (diagnostic knob) lets every bounded poll give up at once: the kernel must finish (no hang), every
-    output must be NaN, and the Python layer must raise -- at the next call into the package, or in check_errors(sync=True)."""
+    """NOCF_DUO_SPIN_MAX=1 (diagnostic knob) lets every bounded poll give up at once: the kernel must finish (no hang), the means must be
+    NaN and the Python layer must raise -- a call whose results are consumed on the host (noMean, intermediates) raises ITSELF, a means
+    call (asynchronous by design: no host synchronisation on the path) at the next call into the package or in check_errors(sync=True)."""
     g = load_golden("swarm50")
     net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
     x = g.t("x").to(DEV)
@@ -176,9 +181,13 @@ def test_a_timed_out_exchange_raises_and_poisons_the_outputs(monkeypatch):
     with pytest.raises(RuntimeError, match="timed out"):
         na.check_errors(sync=True)
     with torch.no_grad():
-        _, csn = na.OCflow(x, net, prob, [0.0, 1.0], 6, "rk4", g.meta["alph"], noMean=True)
+        with pytest.raises(RuntimeError, match="timed out"):
+            na.OCflow(x, net, prob, [0.0, 1.0], 6, "rk4", g.meta["alph"], noMean=True)
+        with pytest.raises(RuntimeError, match="timed out"):
+            na.OCflow(x, net, prob, [0.0, 1.0], 6, "rk4", g.meta["alph"], intermediates=True)
+        Jc, cs = na.OCflow(x, net, prob, [0.0, 1.0], 6, "rk4", g.meta["alph"])
     torch.cuda.synchronize()
-    assert all(torch.isnan(c).all() for c in csn)
+    assert torch.isnan(Jc)
     monkeypatch.delenv("NOCF_DUO_SPIN_MAX")
     with pytest.raises(RuntimeError, match="timed out"):             # the failed call's status has arrived: the next call raises
         na.OCflow(x, net, prob, [0.0, 1.0], 6, "rk4", g.meta["alph"])
@@ -186,6 +195,59 @@ def test_a_timed_out_exchange_raises_and_poisons_the_outputs(monkeypatch):
         Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], 6, "rk4", g.meta["alph"])
     na.check_errors(sync=True)
     assert torch.isfinite(Jc)
+
+
+def test_a_timed_out_training_step_poisons_the_gradients(monkeypatch):
+    """the same knob on the training path: forward tape + split-role adjoint; the parameter gradients must come out NaN (never
+    garbage that an optimizer would apply) and the check must raise"""
+    g = load_golden("swarm50")
+    net, prob = make_net(g, DEV).train(), make_prob(g, DEV, training=True)
+    x = g.t("x")[:24].to(DEV)
+    monkeypatch.setenv("NOCF_DUO", "1")
+    monkeypatch.setenv("NOCF_DUO_SPIN_MAX", "1")
+    Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], 4, "rk4", g.meta["alph"])
+    try:
+        Jc.backward()
+    except RuntimeError as ex:                                       # (the forward's status may arrive before the backward starts)
+        assert "timed out" in str(ex)
+    else:
+        torch.cuda.synchronize()
+        assert all(torch.isnan(p.grad).all() for p in net.parameters())
+        with pytest.raises(RuntimeError, match="timed out"):
+            na.check_errors(sync=True)
+    monkeypatch.delenv("NOCF_DUO_SPIN_MAX")
+    try:
+        na.check_errors(sync=True)
+    except RuntimeError:
+        pass
+
+
+def test_probation_falls_back_to_the_tile_kernel_in_process():
+    """a process whose FIRST split-role launches time out (a GPU shared with another rank or job) switches itself to the per-tile kernels
+    and repeats the call -- a fresh launch, no re-exec -- instead of handing out NaN: run in a child (the switch is per process)"""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, torch\n"
+        "sys.path.insert(0, os.environ['NOCF_REPO']); sys.path.insert(0, os.path.join(os.environ['NOCF_REPO'], 'tests'))\n"
+        "import neuraloc_amd as na\n"
+        "from neuraloc_amd import _lib\n"
+        "from conftest import load_golden\n"
+        "from util_hip import make_net, make_prob\n"
+        "dev = torch.device('cuda:0'); g = load_golden('swarm50')\n"
+        "net, prob = make_net(g, dev), make_prob(g, dev, training=False); x = g.t('x').to(dev)\n"
+        "with torch.no_grad():\n"
+        "    Jc, cs = na.OCflow(x, net, prob, [0.0, 1.0], 6, 'rk4', g.meta['alph'])\n"
+        "    k = _lib.lib().nocf_last_rollout_kernel().decode()\n"
+        "    Jt, _ = na.OCflow(x, net.train(), prob, [0.0, 1.0], 6, 'rk4', g.meta['alph'])\n"
+        "na.check_errors(sync=True)\n"
+        "print('FALLBACK-OK', k, float(Jc))\n"
+        "assert torch.isfinite(Jc) and k.startswith('rollout_kernel')\n")
+    env = dict(os.environ)
+    env.update({"NOCF_REPO": REPO, "NOCF_DUO_PROBATION": "3", "NOCF_DUO_SPIN_MAX": "1", "NOCF_DUO": "1", "NOCF_JIT": "0"})
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FALLBACK-OK" in r.stdout, f"rc {r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}"
+    assert "switching this process to the per-tile kernels" in r.stderr
 
 
 def _record(x, net, prob, nt, alph):
@@ -320,7 +382,7 @@ def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt,
     x = (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 5)).contiguous().to(DEV)
     out = {}
     for rec in ("1", "0"):
-        monkeypatch.setenv("NOCF_ACT_REC", rec)
+        monkeypatch.setenv("NOCF_ACT_REC", rec)                        # "1": the tape + the split-role adjoint (nocf_duo_bwd.inc); "0": recompute, per tile
         net = make_net(g, DEV).train()
         prob = make_prob(g, DEV, training=True)
         xx = x.clone().requires_grad_(True)
@@ -329,6 +391,7 @@ def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt,
         Jc.backward()
         torch.cuda.synchronize()
         na.check_errors(sync=True)
+        assert _kernel() == ("rollout_duo_bwd_kernel" if rec == "1" else "rollout_duo_kernel")
         out[rec] = (float(Jc.detach()), [p.grad.detach().clone() for p in net.parameters()], xx.grad.detach().clone())
     a, b = out["1"], out["0"]
     assert a[0] == b[0]
@@ -336,3 +399,79 @@ def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt,
         scale = float(gb.abs().max())
         assert torch.isfinite(ga).all() and float((ga - gb).abs().max()) <= 2e-4 * scale + 1e-12, (float((ga - gb).abs().max()), scale)
     assert float((a[2] - b[2]).abs().max()) <= 2e-4 * float(b[2].abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("n,nt,stepper,training", [(16, 3, "rk4", True), (37, 2, "rk4", False), (530, 2, "rk4", True), (20, 5, "rk1", True)])
+def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, monkeypatch):
+    """the split-role adjoint against BOTH per-tile adjoints (with the activation record and recomputing) on the pretrained swarm50 network
+    with every multiplier switched on (the checkpoint trains with alph[3:6] = 0: HJt / HJfin / HJgrad exercise the sign masks, the
+    terminal block and the value's rows) and the swarm squeezed so that agents interact and sit inside the obstacles' supports
+    (the physics pass of role B' runs; unsqueezed most rows skip it)."""
+    g = load_golden("swarm50")
+    m = g.meta
+    alph = list(m["alph"])
+    alph[3], alph[4], alph[5] = 2.0, 3.0, 1.5
+    x = (0.3 * (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 9))).contiguous().to(DEV)
+    out = {}
+    for tag, env in (("tape", {}), ("tile+record", {"NOCF_DUO_BWD": "0"}), ("recompute", {"NOCF_ACT_REC": "0"})):
+        monkeypatch.delenv("NOCF_DUO_BWD", raising=False)
+        monkeypatch.delenv("NOCF_ACT_REC", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = make_net(g, DEV).train()
+        prob = make_prob(g, DEV, training=training)
+        xx = x.clone().requires_grad_(True)
+        Jc, _ = na.OCflow(xx, net, prob, [0.0, 1.0], nt, stepper, alph)
+        Jc.backward()
+        torch.cuda.synchronize()
+        na.check_errors(sync=True)
+        assert _kernel() == ("rollout_duo_bwd_kernel" if tag == "tape" else "rollout_duo_kernel")
+        out[tag] = (float(Jc.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()}, xx.grad.detach().clone())
+    ref = out["recompute"]
+    for tag in ("tape", "tile+record"):
+        got = out[tag]
+        assert got[0] == ref[0]
+        for k in ref[1]:
+            scale = float(ref[1][k].abs().max())
+            err = float((got[1][k] - ref[1][k]).abs().max())
+            assert torch.isfinite(got[1][k]).all() and err <= 2e-4 * scale + 1e-12, f"{tag} {k}: {err:g} at scale {scale:g}"
+        assert float((got[2] - ref[2]).abs().max()) <= 2e-4 * float(ref[2].abs().max()) + 1e-12, tag
+
+
+@pytest.mark.parametrize("name,n,stepper,training", [("midcross20", 9, "rk4", True), ("swarm", 6, "rk4", True), ("swap12", 7, "rk1", True),
+                                                      ("midcross30", 5, "rk4", False), ("softcorridor", 11, "rk4", True), ("swap2", 4, "rk4", True)])
+def test_tape_adjoint_on_other_problems_against_oracle_fp64_autograd(name, n, stepper, training):
+    """m = 512 networks on other Cross2D / SwarmTraj problems (2 ... 30 agents, obstacles of both kinds, pair and many-agent interaction
+    forms, d + 1 from 5 to 61): forward tape + split-role adjoint vs the oracle differentiated by torch autograd in float64"""
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(11)
+    prob, x0, _, _ = na.initProb(name, 24, 24, 0.5, alph, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    x0 = x0[:n].contiguous()
+    d = x0.shape[1]
+    sd = synth_state_dict(2, 512, d, seed=len(name))
+    net = na.Phi(nTh=2, m=512, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    nt = 4
+    Jc, _ = na.OCflow(x0, net, prob, [0.0, 1.0], nt, stepper, alph)
+    assert _kernel() == "rollout_duo_kernel"
+    Jc.backward()
+    torch.cuda.synchronize()
+    na.check_errors(sync=True)
+    assert _kernel() == "rollout_duo_bwd_kernel"
+    P = orc.PhiParams.from_state_dict({k: v.clone() for k, v in sd.items()}, dtype=torch.float64)
+    for t in [*P.K, *P.b, P.w, P.A, P.cw, P.cb]:
+        t.requires_grad_(True)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    J, _ = orc.rollout(x0.double().cpu(), P, S.to(torch.float64), [0.0, 1.0], nt, stepper, alph)
+    J.backward()
+    want = {"A": P.A.grad, "c.weight": P.cw.grad, "c.bias": P.cb.grad, "w.weight": P.w.grad,
+            "N.layers.0.weight": P.K[0].grad, "N.layers.0.bias": P.b[0].grad, "N.layers.1.weight": P.K[1].grad, "N.layers.1.bias": P.b[1].grad}
+    assert abs(Jc.item() - float(J)) <= 2e-5 * abs(float(J))
+    for k, p in net.named_parameters():
+        w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()
+        scale = w.abs().max().item()
+        err = (p.grad.cpu().double() - w.reshape(p.shape)).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-6, f"{name} {k}: err {err:g} at scale {scale:g}"

@@ -89,3 +89,21 @@ def test_bench_line_under_the_distributed_launcher_with_one_rank():
               "config", "roofline"):
         assert k in line
     assert line["n_gpus"] == 1 and line["roofline"]["kernel"] == "rollout_duo_kernel" and line["value"] > 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its two ranks itself (before it touches the GPU) and
+    relays rank 0's line.  Two ranks share the one GPU of the test box, so the reductions go through gloo (NOCF_BENCH_BACKEND) and the
+    weight-stationary kernels -- which need the whole device -- may time out against each other: the probation switch (neuraloc_amd._lib
+    duo_guard) then moves a rank to the per-tile kernels in-process.  Either way the line must be there and say 2 ranks."""
+    import json
+    env = dict(os.environ)
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), "NOCF_BENCH_BACKEND": "gloo",
+                "NOCF_DUO_PROBATION": "3"})
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-other-workloads"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"].startswith("gloo") and line["value"] > 0
+    assert line["config"]["rows_per_gpu"] == 512 and line["scaling"] == "strong"
