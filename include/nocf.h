@@ -96,9 +96,11 @@ int nocf_version(void);
  * "rollout_lane_kernel", or "none"); a static string, not thread-safe (bench.py labels its roofline with it) */
 const char* nocf_last_rollout_kernel(void);
 
-/* Asynchronous status of the last nocf_rollout_f32 / nocf_rollout_record_f32 call of this process.  The split-role kernel's
- * workgroups wait for each other with bounded polls; when one times out (the GPU was shared with another kernel, so that not all
- * workgroups were resident) the kernel sets an error word, finishes, and every output row and mean is NaN.  This call enqueues a
+/* Asynchronous status of the last rollout / adjoint call of THIS THREAD (per-call state is thread-local: one host thread per device
+ * is the supported threading model).  The split-role kernels' workgroups wait for each other with bounded polls; when one times out
+ * (the GPU was shared with another kernel, so that not all workgroups were resident) the kernel sets an error word, finishes, and
+ * every output of the call -- persample rows, the cost sums, z_out, zFull, ctrlFull -- is turned into NaN on the stream (the training
+ * tape and s_all are not: call nocf_poison_if_failed_f32 on what is derived from them).  This call enqueues a
  * 4-byte device-to-host copy of that word into `host_word` (pinned host memory) on `stream`; once the stream has reached it,
  * *host_word != 0 means the rollout failed (0x3000 + the exchange kind that timed out).  Returns 1 when a copy was enqueued, 0 when
  * the last rollout kernel has no such word (*host_word is set to 0), or an error code.  The Python layer raises RuntimeError from it. */

@@ -47,6 +47,21 @@ class ResNN(nn.Module):
         raise NotImplementedError("ResNN is evaluated inside the fused HIP kernels; call Phi(x) / Phi.getGrad(x)")
 
 
+
+_WS_POOL = 4
+
+
+def _pool_get(pool, key, nbytes, dev):
+    """workspace of at least nbytes for (device, stream): most recently used last, at most _WS_POOL entries"""
+    ws = pool.pop(key, None)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pool[key] = ws
+    while len(pool) > _WS_POOL:
+        pool.pop(next(iter(pool)))
+    return ws
+
+
 class Phi(nn.Module):
     """Phi(x,t) = w' N([x;t]) + 1/2 [x;t]' A'A [x;t] + c'[x;t] + c_b   (src/Phi.py:56-138)."""
 
@@ -94,17 +109,17 @@ class Phi(nn.Module):
         st.cw = dv(self.c.weight, "c.weight")
         st.cb = 0.0
         st.cb_dev = dv(self.c.bias, "c.bias")           # read on the device: no device-to-host copy (a sync) per call
-        # One workspace per module AND STREAM (every call repacks it and the kernels scribble in it while they run): calls on the
-        # same Phi from two streams each get their own and cannot race.
+        # One workspace per module AND STREAM (every call repacks it and the kernels scribble in it while they run): calls on the same
+        # Phi from two streams do not share scratch memory.  That makes them memory-safe, not concurrent: the weight-stationary kernels
+        # (m = 512: split-role; m <= 128: one-CU) assume the device to themselves -- the split-role kernel needs every CU, two of them at
+        # once push each other into the exchange timeout (the call then raises, include/nocf.h).  The pool keeps the _WS_POOL most
+        # recently used workspaces (about 50 MB each for a 2048-row swarm50 batch) and is not copied by deepcopy / pickle.
         nbytes = _lib.lib().nocf_rollout_workspace_bytes(self.d, self.m, self.nTh, int(n))
         if nbytes == 0:
             raise RuntimeError("nocf_workspace_bytes: unsupported (d, m, nTh)")
         if self._ws is None:
             self._ws = {}
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _pool_get(self._ws, (dev.index, torch.cuda.current_stream(dev).cuda_stream), nbytes, dev)
         return st, keep, ws
 
     def _c_struct64(self):
@@ -139,11 +154,14 @@ class Phi(nn.Module):
         pool = getattr(self, "_ws64", None)
         if pool is None:
             pool = self._ws64 = {}
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)        # (per stream: see _c_struct)
-        ws = pool.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = pool[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _pool_get(pool, (dev.index, torch.cuda.current_stream(dev).cuda_stream), nbytes, dev)        # (per stream: see _c_struct)
         return st, keep, ws
+
+    def __getstate__(self):
+        st = self.__dict__.copy()                        # (scratch memory is not state: deepcopy / pickle leave it behind)
+        st["_ws"] = None
+        st.pop("_ws64", None)
+        return st
 
     def _phi64(self, x, value):
         """Phi(s) (n-by-1) or grad Phi (n-by-(d+1)) in double precision (nocf_phi_f64)"""

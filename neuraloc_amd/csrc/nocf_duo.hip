@@ -105,8 +105,20 @@ static_assert(sizeof(DuoPlan) % 4 == 0 && sizeof(DuoPlan) / 4 <= 256, "plan copy
 //   W3[c][w][kb][lane] = K1[16kb + 4(lane/16) + q][64c+16w + lane%16]          (P3: out j, contraction i)
 //   K1[c][w][kb][lane] = K0[64c+16w + lane%16][16kb + 4(lane/16) + q]          (P1: out i, contraction dim)
 //   K4[c][mt][kb][lane] = K0[64c + 16kb + 4(lane/16) + q][16mt + lane%16]      (P4: out dim, contraction i in H_c)
-__global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws) {
+// ... and (one launch instead of four) clears the error words (first chunk of a call), the XCC table and the CU census, and fills the
+// exchange area with the sentinel
+__global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, int clear_err) {
     float4* ws4 = reinterpret_cast<float4*>(ws);
+    {
+        const long stride_ = (long)gridDim.x * blockDim.x, gid_ = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        unsigned* wu = reinterpret_cast<unsigned*>(ws);
+        if (clear_err) for (long i = gid_; i < 64; i += stride_) wu[dp.oErr + i] = 0u;
+        for (long i = gid_; i < 32 * 16 + 8 * 520; i += stride_) wu[dp.oXcc + i] = 0u;
+        uint4* x4 = reinterpret_cast<uint4*>(wu + dp.oX);                       // (oX and xStride are multiples of 64 words)
+        const long nx4 = (long)dp.ngroups * dp.xStride / 4;
+        const uint4 sen = make_uint4(DU_SENT, DU_SENT, DU_SENT, DU_SENT);
+        for (long i = gid_; i < nx4; i += stride_) x4[i] = sen;
+    }
     const int m = 64 * DU_G, D1 = dp.D1;
     const long nW = (long)DU_G * 4 * DU_KBM * 64, nK1 = (long)DU_G * 4 * DU_KBD * 64, nK4 = (long)DU_G * DU_KBD * 4 * 64;
     const long total = 2 * nW + nK1 + nK4;
@@ -453,13 +465,17 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             if (group < dp.ngroups) {
                 sl = (int)atomicAdd(cen + 8 + key, 1u);
                 if (sl == 0) { rank = (int)atomicAdd(cen + 1, 1u); __hip_atomic_store(cen + 264 + key, (unsigned)rank + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                // (a key that receives a THIRD workgroup -- the key holds SE / SH / CU, so workgroups of one slot on two XCDs would share
+                // keys -- still satisfies #CUs x 2 = #workgroups with counts like 1 and 3: it switches the census map off for the slot)
+                if (sl > 1) atomicExch(cen + 2, 1u);
                 atomicAdd(cen + 0, 1u);
                 int spins = 0;
                 while ((int)__hip_atomic_load(cen + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
                     __builtin_amdgcn_s_sleep(4);
                     if (++spins > dp.spin_max) { atomicExch(reinterpret_cast<unsigned*>(ws) + dp.oErr, 0x3000u + DUK_XCC); break; }
                 }
-                ok = spins <= dp.spin_max && (int)__hip_atomic_load(cen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 2 == nwg;
+                ok = spins <= dp.spin_max && (int)__hip_atomic_load(cen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 2 == nwg &&
+                     __hip_atomic_load(cen + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
                 if (ok && sl != 0) {
                     spins = 0;
                     unsigned r1 = 0;
@@ -1252,10 +1268,10 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
         dp.mapmode = du_env_int("NOCF_DUO_MAP", 3);                 // bit 0: A / B of a member adjacent in the static map; bit 1: CU census (see the kernel)
         dp.dbg = du_env_int("NOCF_DUO_DBG", 0);
         dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
-        hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws);     // (every chunk: the plan record changes with the chunk's rows)
-        if (r0 == 0) { e = hipMemsetAsync(ws + dp.oErr, 0, 64 * 4, st); if (e) return (int)e; }
-        e = hipMemsetAsync(ws + dp.oXcc, 0, (32 * 16 + 8 * 520) * 4, st); if (e) return (int)e;      // XCC table + CU census
-        e = hipMemsetAsync(ws + dp.oX, 0xFF, (size_t)dp.ngroups * dp.xStride * 4, st);            // every exchange word starts as the sentinel
+        // (every chunk: the plan record changes with the chunk's rows; the same launch clears the error words / tables and fills the
+        // exchange area with the sentinel)
+        hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws, r0 == 0 ? 1 : 0);
+        e = hipGetLastError();
         if (e) return (int)e;
         RollArgs ra = ra_in;
         ra.x = ra_in.x + r0 * phi->d; ra.n = cn;
@@ -1317,10 +1333,8 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
         dp.mapmode = du_env_int("NOCF_DUO_MAP", 3);
         dp.dbg = du_env_int("NOCF_DUO_DBG", 0);
         dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
-        hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws);
-        if (r0 == 0) { e = hipMemsetAsync(ws + dp.oErr, 0, 64 * 4, st); if (e) return (int)e; }
-        e = hipMemsetAsync(ws + dp.oXcc, 0, (32 * 16 + 8 * 520) * 4, st); if (e) return (int)e;
-        e = hipMemsetAsync(ws + dp.oX, 0xFF, (size_t)dp.ngroups * dp.xStride * 4, st);
+        hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws, r0 == 0 ? 1 : 0);
+        e = hipGetLastError();
         if (e) return (int)e;
         DuoBwdArgs ba;
         ba.sAll = h.s_all; ba.zT = h.z_final; ba.hs = h.hs; ba.tape = h.tape; ba.tapeU1 = h.tapeU1; ba.tapeSc = h.tapeSc;

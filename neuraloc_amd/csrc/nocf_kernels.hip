@@ -1504,6 +1504,12 @@ __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float* __restr
     }
 }
 
+// turns a buffer into NaN when a rollout's error word is set (a timed-out exchange of a split-role kernel); returns at once otherwise
+__global__ void poison_kernel(float* __restrict__ buf, long count, const unsigned* __restrict__ errp) {
+    if (__builtin_nontemporal_load(errp) == 0u) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) buf[i] = __uint_as_float(0x7fc00000u);
+}
+
 __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* __restrict__ b, int K, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1657,10 +1663,13 @@ static int check_phi(const NocfPhi* phi) {
 
 // ---- optional in-library timing of the rollout kernel (bench.py): HIP events recorded on the
 // launch stream immediately around the kernel, so the figure is the kernel's own duration.
-static const unsigned* g_last_errp = nullptr;         // device address of the last rollout's error word (split-role kernel), or null
-static const char* g_last_kernel = "none";           // measurement hook: which rollout kernel the last call launched (nocf_last_rollout_kernel)
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
-static bool g_prof_on = false;
+// Per-THREAD call state (a host thread per device is the supported threading model: two threads driving two GPUs never see each
+// other's error word, kernel name or timing events; there is no other mutable state in the library besides the cached knobs, which
+// are read under a mutex)
+static thread_local const unsigned* g_last_errp = nullptr;   // device address of the last rollout's error word (split-role kernels), or null
+static thread_local const char* g_last_kernel = "none";      // measurement hook: which rollout kernel the last call launched (nocf_last_rollout_kernel)
+static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static thread_local bool g_prof_on = false;
 static unsigned long long* g_stamp_buf = nullptr;     // diagnostic builds only (nocf_debug_set_stamp_buffer)
 
 extern "C" {
@@ -1729,9 +1738,17 @@ int nocf_rollout_bwd_small_f32(const NocfPhi* phi, const NocfProb* prob, int64_t
     const int DPsel = phi->d + 1 <= 8 ? 8 : (phi->d + 1 <= 16 ? 16 : 32);
     if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] lane adjoint kernel\n");
 #define NOCF_LANEB_LAUNCH(MPV, DPV) hipLaunchKernelGGL((rollout_lane_bwd_kernel<MPV, DPV>), dim3(grid), dim3(256), 0, st, la, pb)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_prof_on) {
+        if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+        (void)hipEventRecord(ev0, st);
+    }
     if (MPsel == 16) { if (DPsel == 8) NOCF_LANEB_LAUNCH(16, 8); else if (DPsel == 16) NOCF_LANEB_LAUNCH(16, 16); else NOCF_LANEB_LAUNCH(16, 32); }
     else             { if (DPsel == 8) NOCF_LANEB_LAUNCH(32, 8); else if (DPsel == 16) NOCF_LANEB_LAUNCH(32, 16); else NOCF_LANEB_LAUNCH(32, 32); }
 #undef NOCF_LANEB_LAUNCH
+    if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
+    g_last_kernel = "rollout_lane_bwd_kernel";
+    g_last_errp = nullptr;
     return (int)hipGetLastError();
 }
 
@@ -1918,6 +1935,11 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
                 e = hipGetLastError();
                 if (e) return (int)e;
             }
+            // a timed-out exchange: every other output the caller asked for becomes NaN too (one tiny launch each; they return at once
+            // when the error word is clear)
+            if (z_out) hipLaunchKernelGGL(poison_kernel, dim3(1024), dim3(256), 0, st, z_out, (long)n * (phi->d + 4), errp);
+            if (zFull) hipLaunchKernelGGL(poison_kernel, dim3(1024), dim3(256), 0, st, zFull, (long)(nt + 1) * n * (phi->d + 4), errp);
+            if (ctrlFull) hipLaunchKernelGGL(poison_kernel, dim3(1024), dim3(256), 0, st, ctrlFull, (long)(nt + 1) * n * ra.cdim, errp);
             return 0;
         }
         if (g_prof_on) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr; }
@@ -2098,16 +2120,10 @@ int nocf_rollout_tape_f32(const NocfPhi* phi, const NocfProb* prob, const float*
                         workspace, workspace_bytes, stream, s_all, tape, recorded, tape + oU1, tape + oSc);
 }
 
-__global__ void poison_kernel(float* __restrict__ buf, long count, const unsigned* __restrict__ errp) {
-    if (*errp == 0u) return;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) buf[i] = __uint_as_float(0x7fc00000u);
-}
-
 int nocf_poison_if_failed_f32(float* buf, int64_t count, void* stream) {
     if (!buf) return NOCF_E_NULL;
     if (!g_last_errp || count < 1) return 0;
-    hipLaunchKernelGGL(poison_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, buf, (long)count, g_last_errp);
+    hipLaunchKernelGGL(poison_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, buf, (long)count, g_last_errp);
     return (int)hipGetLastError();
 }
 
@@ -2214,9 +2230,17 @@ static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n,
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e) return (int)e;
     {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (g_prof_on) {
+            if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+            (void)hipEventRecord(ev0, st);
+        }
         void* args[] = {(void*)&plp, (void*)&pb, (void*)&ws, (void*)&ba};
         e = hipLaunchKernel(fk, dim3((int)((n + 3) / 4)), dim3(pl.nwaves * 64), args, ldsBytes, st);
         if (e) return (int)e;
+        if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
+        g_last_kernel = "rollout_bwd_kernel";
+        g_last_errp = nullptr;
     }
     return (int)hipGetLastError();
 }
