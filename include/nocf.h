@@ -96,8 +96,9 @@ int nocf_version(void);
  * "rollout_lane_kernel", or "none"); a static string, not thread-safe (bench.py labels its roofline with it) */
 const char* nocf_last_rollout_kernel(void);
 
-/* Asynchronous status of the last rollout / adjoint call of THIS THREAD (per-call state is thread-local: one host thread per device
- * is the supported threading model).  The split-role kernels' workgroups wait for each other with bounded polls; when one times out
+/* Asynchronous status of the last rollout / adjoint call on the calling thread's CURRENT DEVICE (per-call state is kept per device:
+ * threads driving different GPUs do not see each other's; a backward that a framework runs on a worker thread shares the forward's).
+ * The split-role kernels' workgroups wait for each other with bounded polls; when one times out
  * (the GPU was shared with another kernel, so that not all workgroups were resident) the kernel sets an error word, finishes, and
  * every output of the call -- persample rows, the cost sums, z_out, zFull, ctrlFull -- is turned into NaN on the stream (the training
  * tape and s_all are not: call nocf_poison_if_failed_f32 on what is derived from them).  This call enqueues a
@@ -233,7 +234,7 @@ int nocf_rollout_bwd_act_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
  *     dc.weight = colsum Gb + phib'sT,  d(A'A) = Gb'Sx + (sT.phib)'sT / 2,  phib = alph4 sign(tape scalar of the terminal block) / n_total.
  *   lam0 device [n, d] = dJc/dx0 (nullable).  Returns NOCF_E_SHAPE when the shape / problem / residency does not qualify (nothing launched).
  *   A timed-out exchange is reported like the forward's (nocf_last_rollout_status_async); nocf_poison_if_failed_f32 turns a buffer
- *   into NaN on the stream if the last launch of this thread failed (call it on the gradients before they are used).
+ *   into NaN on the stream if the last launch on this device failed (call it on the gradients before they are used).
  */
 size_t nocf_tape_floats(int32_t d, int32_t m, int32_t nTh, int64_t n, int32_t nt, int32_t stepper);
 int nocf_rollout_tape_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,

@@ -1097,6 +1097,10 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     thv = du_ld(g, vb, xT + fo);
                 };
                 const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DB_VF >> 2) + lane, mid);
+                // (the first look at the tanh(o) answer stays BEHIND the product: left to itself the scheduler hoists the sentinel test into
+                // the MFMA stream, two k-blocks behind the request, behind an s_waitcnt vmcnt(0) that also waits for the three resets'
+                // acknowledgements)
+                asm volatile("" : "+v"(thv));
                 DTL(40 * t + 26);
                 {
                     int spins = 0;

@@ -1663,13 +1663,27 @@ static int check_phi(const NocfPhi* phi) {
 
 // ---- optional in-library timing of the rollout kernel (bench.py): HIP events recorded on the
 // launch stream immediately around the kernel, so the figure is the kernel's own duration.
-// Per-THREAD call state (a host thread per device is the supported threading model: two threads driving two GPUs never see each
-// other's error word, kernel name or timing events; there is no other mutable state in the library besides the cached knobs, which
-// are read under a mutex)
-static thread_local const unsigned* g_last_errp = nullptr;   // device address of the last rollout's error word (split-role kernels), or null
-static thread_local const char* g_last_kernel = "none";      // measurement hook: which rollout kernel the last call launched (nocf_last_rollout_kernel)
-static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
-static thread_local bool g_prof_on = false;
+// Per-DEVICE call state (the error word of the last rollout, which kernel it was, the timing events of a profile window), keyed by the
+// current HIP device of the calling thread: two host threads driving two GPUs never see each other's state, and the thread PyTorch's
+// autograd engine runs a backward on shares the state of the thread that launched the forward on that device.  (Two threads driving
+// ONE device concurrently are not supported: the weight-stationary kernels need the whole device.)  There is no other mutable state
+// in the library besides the cached knobs, which are read under a mutex.
+struct CallState {
+    const unsigned* errp = nullptr;     // device address of the last rollout's error word (split-role kernels), or null
+    const char* kernel = "none";        // measurement hook: which rollout kernel the last call launched (nocf_last_rollout_kernel)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    bool prof_on = false;
+};
+static CallState g_call_state[64];
+static CallState& call_state() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return g_call_state[dev & 63];
+}
+#define g_last_errp (call_state().errp)
+#define g_last_kernel (call_state().kernel)
+#define g_prof_events (call_state().events)
+#define g_prof_on (call_state().prof_on)
 static unsigned long long* g_stamp_buf = nullptr;     // diagnostic builds only (nocf_debug_set_stamp_buffer)
 
 extern "C" {

@@ -79,7 +79,7 @@ def test_duo_matches_tile_kernel_and_oracle_on_swarm50(n, training, variant, mon
     assert not torch.isnan(duo).any()
     monkeypatch.setenv("NOCF_DUO", "0")
     tile = _table(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"])
-    allowed = max(2, n // 128)
+    allowed = max(2, n // 256)          # (what the fp64 demonstration below shows: 8 such rows in 4096)
     assert _flips(duo, tile) <= allowed, f"split-role vs tile kernel: {_flips(duo, tile)} samples differ"
     keep = ~((duo.double() - tile.double()).abs() > 1e-3 + 1e-3 * tile.double().abs()).any(dim=1)
     for j in range(7):                                   # batch means over the rows that are not chaotic / mask-flipped
@@ -391,7 +391,7 @@ def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt,
         Jc.backward()
         torch.cuda.synchronize()
         na.check_errors(sync=True)
-        assert _kernel() == ("rollout_duo_bwd_kernel" if rec == "1" else "rollout_duo_kernel")
+        assert _kernel() == ("rollout_duo_bwd_kernel" if rec == "1" else "rollout_bwd_kernel")
         out[rec] = (float(Jc.detach()), [p.grad.detach().clone() for p in net.parameters()], xx.grad.detach().clone())
     a, b = out["1"], out["0"]
     assert a[0] == b[0]
@@ -425,7 +425,7 @@ def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, m
         Jc.backward()
         torch.cuda.synchronize()
         na.check_errors(sync=True)
-        assert _kernel() == ("rollout_duo_bwd_kernel" if tag == "tape" else "rollout_duo_kernel")
+        assert _kernel() == ("rollout_duo_bwd_kernel" if tag == "tape" else "rollout_bwd_kernel")
         out[tag] = (float(Jc.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()}, xx.grad.detach().clone())
     ref = out["recompute"]
     for tag in ("tape", "tile+record"):
@@ -475,3 +475,48 @@ def test_tape_adjoint_on_other_problems_against_oracle_fp64_autograd(name, n, st
         scale = w.abs().max().item()
         err = (p.grad.cpu().double() - w.reshape(p.shape)).abs().max().item()
         assert err <= 2e-4 * scale + 1e-6, f"{name} {k}: err {err:g} at scale {scale:g}"
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_rows_that_differ_between_two_kernels_are_sensitive_in_the_fp64_oracle(training, monkeypatch, capsys):
+    """The allowance of the sweep above ("a few swarm50 states are chaotic at nt = 10") demonstrated instead of asserted: on 4096 rows the
+    rows on which the split-role kernel and the per-tile kernel disagree (beyond rel 1e-3 + abs 1e-3) are taken to the ORACLE IN FLOAT64
+    and integrated twice, from x and from x (1 + 1e-6): every one of them must move there by more than the same threshold -- i.e. the
+    row amplifies a 1e-6 perturbation of its input past the tolerance in exact arithmetic too, so two correct fp32 evaluations (different
+    summation orders, 6e-8 per operation) cannot be expected to agree on it -- while a control group of rows on which the kernels agree
+    does not.  The number of such rows is printed and bounded by what this shows (4096 rows: at most 12)."""
+    n, nt = 4096, 10
+    g = load_golden("swarm50")
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=training)
+    m = g.meta
+    x = (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 3)).contiguous()
+    monkeypatch.setenv("NOCF_DUO", "1")
+    duo = _table(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"])
+    assert _kernel() == "rollout_duo_kernel"
+    monkeypatch.setenv("NOCF_DUO", "0")
+    tile = _table(x.to(DEV), net, prob, [0.0, 1.0], nt, "rk4", m["alph"])
+    off = ((duo.double() - tile.double()).abs() > 1e-3 + 1e-3 * tile.double().abs()).any(dim=1).cpu()
+    rows = torch.nonzero(off).flatten()
+    P, S = make_oracle(g, training)
+    P64 = orc.PhiParams.from_state_dict(g.state_dict(), dtype=torch.float64)
+    S64 = S.to(torch.float64)
+
+    def moved(idx):
+        xs = x[idx].double()
+        a = orc.persample_table(xs, P64, S64, [0.0, 1.0], nt, "rk4", m["alph"])
+        b = orc.persample_table(xs * (1.0 + 1e-6), P64, S64, [0.0, 1.0], nt, "rk4", m["alph"])
+        return ((a - b).abs() > 1e-3 + 1e-3 * a.abs()).any(dim=1), ((a - b).abs() / (1e-3 + 1e-3 * a.abs())).amax(dim=1)
+
+    with capsys.disabled():
+        print(f"\n[chaotic rows] training={training}: {len(rows)} of {n} rows differ between the split-role and the per-tile kernel: {rows.tolist()}")
+    assert len(rows) <= 12, f"{len(rows)} rows differ"
+    if len(rows):
+        mv, amp = moved(rows)
+        with capsys.disabled():
+            print("[chaotic rows]   fp64 oracle, x vs x(1+1e-6): change / tolerance per differing row:", [f"{float(v):.1f}" for v in amp])
+        assert bool(mv.all()), f"rows {rows[~mv].tolist()} differ between the kernels but are NOT sensitive in the fp64 oracle"
+    ctrl = torch.nonzero(~off).flatten()[:: max(1, (n - len(rows)) // 64)][:64]
+    mv, amp = moved(ctrl)
+    with capsys.disabled():
+        print(f"[chaotic rows]   control ({len(ctrl)} agreeing rows): {int(mv.sum())} sensitive, largest change / tolerance {float(amp.max()):.3f}")
+    assert int(mv.sum()) <= 2
