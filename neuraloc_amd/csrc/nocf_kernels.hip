@@ -2369,6 +2369,9 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob, const double*
     ra.x = x; ra.n = n; ra.t0 = t0; ra.t1 = t1; ra.h = (t1 - t0) / nt; ra.nt = nt; ra.stepper = stepper; ra.a0 = alph[0];
     ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull;
     ra.cdim = nocf_ctrl_dim(&p32, phi->d);
+#ifdef NOCF_STAMPS
+    { const int dbg = env_int("NOCF_F64_DBG", 0); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f64_dbg), &dbg, sizeof(dbg)); }
+#endif
     const size_t ldsBytes = (size_t)pl.ldsDoubles * 8;
     const bool wide = phi->m > 256;
     const void* fk = wide ? (T == 4 ? reinterpret_cast<const void*>(rollout_f64_kernel<4, true>)
