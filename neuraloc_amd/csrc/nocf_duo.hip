@@ -200,6 +200,11 @@ __device__ __forceinline__ void mfma_v(f32x4& acc, float w, float b) {
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
 }
 #define DU_FENCE2(a, b) asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b))
+// Store-data hazard (found in round 4, tools/store_hazard_check.py): a 128-bit buffer store reads its data registers over several cycles;
+// hipcc's hazard recognizer assumes that a store with an SGPR soffset needs no wait state before a VALU instruction overwrites them, and
+// schedules such a write into the very next slot -- on gfx950 the last lanes of every 16 then store the NEW value (the adjoint's obar
+// stream came out with the y stream's fourth component in lanes 12-15 of every row).  The guard keeps the data live for two more states.
+#define DU_STORE_GUARD(u) asm volatile("s_nop 1" :: "v"(u))
 #define DU_PIN(v) asm volatile("" : "+s"(v))
 
 struct DCtx {
@@ -218,6 +223,7 @@ __device__ __forceinline__ void du_st(const DCtx& g, int vbyte, int sbyte, f32x4
     u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
     if (g.fast) __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 0 /*stays in the XCD's L2*/);
     else __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 16 /*sc1: write-through*/);
+    DU_STORE_GUARD(u);
 }
 __device__ __forceinline__ void du_st_sent(const DCtx& g, int vbyte, int sbyte) {
     const f32x4 sv = {__uint_as_float(DU_SENT), __uint_as_float(DU_SENT), __uint_as_float(DU_SENT), __uint_as_float(DU_SENT)};

@@ -133,6 +133,9 @@ def main():
             r_ = float(dlt.max()) / sc_
             if r_ > worst[0]:
                 worst = (r_, b)
+        if worst[0] > 1e-3:
+            print(f"  {name}: per-block rel diffs", [f"{float((new[b] - old[b]).abs().max()) / (float(old[b].abs().max()) + 1e-30):.1e}" for b in blocks],
+                  " rows off in worst block:", torch.nonzero((new[worst[1]] - old[worst[1]]).abs().amax(dim=1) > 1e-3 * old[worst[1]].abs().max()).flatten().tolist()[:40])
         print(f"  {name:4s}: worst rel diff {worst[0]:.3e} at block {worst[1]}" + (f"; NON-FINITE blocks {nan_blocks[:8]}{'...' if len(nan_blocks) > 8 else ''}" if nan_blocks else ""))
 
     blocks = list(range(total, -1, -1))
@@ -147,6 +150,21 @@ def main():
     cmp("Qb", Qb, oq, blocks)
     cmp("Ob", Ob, oo, blocks)
     cmp("Wb", Wb, ow, blocks)
+    if os.environ.get("DBG_OB"):
+        b_ = total - 1
+        nw, od = Ob.view(E, n, -1)[b_], oo[b_]
+        bad = torch.nonzero((nw - od).abs() > 1e-3 * od.abs().max())
+        print("Ob block", b_, "bad entries", bad.shape[0], "first", bad[:12].tolist())
+        cols = sorted(set(bad[:, 1].tolist()))
+        print("bad columns (count %d):" % len(cols), cols[:40])
+        rows_ = sorted(set(bad[:, 0].tolist()))
+        print("bad rows:", rows_)
+        r0_, c0_ = int(bad[0, 0]), int(bad[0, 1])
+        print("new", nw[r0_, c0_:c0_ + 8].tolist(), "old", od[r0_, c0_:c0_ + 8].tolist())
+        # is the new value some other entry of old?
+        v = float(nw[r0_, c0_])
+        hit = torch.nonzero((od - v).abs() < 1e-6 * abs(v) + 1e-12)
+        print("new value found in old at", hit[:8].tolist())
     dl = (lam0 - olam).abs().max().item() / (olam.abs().max().item() + 1e-30)
     print(f"  lam0: rel diff {dl:.3e} (scale {olam.abs().max().item():.3e}); finite {bool(torch.isfinite(lam0).all())}")
 
