@@ -27,7 +27,11 @@ struct DuoBwdHost {
     float a0, a3, a4, a5, inv_n;
     float *Y, *Ab, *Wb, *Qb, *Ob, *Gb, *lam0;
     unsigned long long* stamps;
+    // optional: dK1 [m][m] and dK0 [m][d+1] accumulated in the kernel (the weight-gradient roles), with a scratch buffer of
+    // duo_dw_scratch_floats() floats for the groups' partial sums; *dw_done = 1 when that kernel ran
+    float *dK1, *dK0, *dw_scratch; size_t dw_scratch_floats; int* dw_done;
 };
+size_t duo_dw_scratch_floats(void);
 int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, float* ws, size_t ws_bytes, hipStream_t st,
                    const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1);
 

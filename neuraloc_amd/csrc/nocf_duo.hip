@@ -93,7 +93,7 @@ struct DuoPlan {
     int d, D1, r, nAg, NT, ngroups, spin_max, fast;
     float hN, cb;
     int mapmode, ldsFloats;
-    int dbg, pad_;                 // (spare)
+    int dbg, dw;                   // dw: the adjoint with the two weight-gradient roles (32 workgroups per group)
     long oW2, oW3, oK1, oK4;        // float4 offsets of the images in the workspace
     long oA, oVec, oCW;             // float offsets: A [16][160], b0 | b1 | w [3][512], c.weight [160]
     long oPlan, oErr, oXcc, oCen, oX, xStride;
@@ -113,7 +113,7 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
         const long stride_ = (long)gridDim.x * blockDim.x, gid_ = (long)blockIdx.x * blockDim.x + threadIdx.x;
         unsigned* wu = reinterpret_cast<unsigned*>(ws);
         if (clear_err) for (long i = gid_; i < 64; i += stride_) wu[dp.oErr + i] = 0u;
-        for (long i = gid_; i < 32 * 16 + 8 * 520; i += stride_) wu[dp.oXcc + i] = 0u;
+        for (long i = gid_; i < 32 * 16 + 8 * 520 + 32 * 32; i += stride_) wu[dp.oXcc + i] = 0u;      // XCC table, CU census, progress counters
         uint4* x4 = reinterpret_cast<uint4*>(wu + dp.oX);                       // (oX and xStride are multiples of 64 words)
         const long nx4 = (long)dp.ngroups * dp.xStride / 4;
         const uint4 sen = make_uint4(DU_SENT, DU_SENT, DU_SENT, DU_SENT);
@@ -1192,25 +1192,27 @@ static int du_env_int(const char* name, int dflt) { return nocf_env_int(name, df
 
 long duo_rows_per_launch(void) { return 32L * 16 * DU_NTMAX; }
 
-static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false) {
+static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false, bool dw = false) {
     if (nTh != 2 || m != 64 * DU_G || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
     DuoPlan dp;
     memset(&dp, 0, sizeof(dp));
     dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents;
     const long ntiles = (n + 15) / 16;
-    dp.ngroups = (int)std::min<long>(32, ntiles);
+    dp.ngroups = (int)std::min<long>(dw ? 16 : 32, ntiles);     // (dw: 32 workgroups per group, 16 groups fill the chip)
+    dp.dw = dw ? 1 : 0;
     dp.NT = (int)((ntiles + dp.ngroups - 1) / dp.ngroups);
     if (dp.NT > DU_NTMAX) return NOCF_E_SHAPE;
     dp.hN = 1.0f;
     if (bwd && r > 10) return NOCF_E_SHAPE;                                        // (the adjoint keeps 10 rows of A in LDS)
     const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE : DA_T + 2 * dp.NT * DS_STRIDE, ldsB = DB_END;
-    dp.ldsFloats = std::max(ldsA, ldsB);
+    dp.ldsFloats = std::max(std::max(ldsA, ldsB), dw ? DC_END : 0);
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
     long o = 0;                                                                    // floats
     dp.oPlan = o; o += 256;
     dp.oErr = o; o += 64;                                                          // (uint index == float index)
     dp.oXcc = o; o += 32 * 16;
     dp.oCen = o; o += 8 * 520;                                                    // CU census of the role map (uints)
+    o += 32 * 32;                                                                  // progress counters of the weight-gradient roles: [group][2] at oCen + 8 * 520, 64 B apart
     const long nW = (long)DU_G * 4 * DU_KBM * 64, nK1 = (long)DU_G * 4 * DU_KBD * 64, nK4 = (long)DU_G * DU_KBD * 4 * 64;   // float4s
     dp.oW2 = o / 4; o += nW * 4;
     dp.oW3 = o / 4; o += nW * 4;
@@ -1309,24 +1311,29 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
 }
 
 // ---- the adjoint (nocf_duo_bwd.inc).  Same plan, same images, same residency rule as the forward.
-template <int PD>
-static const void* duo_bwd_fn() { return reinterpret_cast<const void*>(rollout_duo_bwd_kernel<PD>); }
+template <int PD, bool DW>
+static const void* duo_bwd_fn() { return reinterpret_cast<const void*>(rollout_duo_bwd_kernel<PD, DW>); }
 
 int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, float* ws, size_t ws_bytes, hipStream_t st,
                    const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
     if (pb.kind == NOCF_PROB_QUADCOPTER) return 1;
-    const long chunk = duo_rows_per_launch();
+    // dw: the kernel with the two weight-gradient roles (dK1 / dK0 accumulated in the kernel): 32 workgroups per group, 16 groups,
+    // 1024 rows per launch
+    const bool dw = h.dK1 != nullptr && h.dK0 != nullptr && h.dw_scratch != nullptr && du_env_int("NOCF_DUO_DW", 1) != 0 &&
+                    h.dw_scratch_floats >= duo_dw_scratch_floats();
+    const long chunk = dw ? duo_rows_per_launch() / 2 : duo_rows_per_launch();
     DuoPlan dp0;
-    if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(h.n, chunk), &dp0, true) != 0) return 1;
+    if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(h.n, chunk), &dp0, true, dw) != 0) return 1;
     if (ws_bytes < duo_ws_bytes_of(dp0)) return 1;
-    const void* fk = pb.kind == NOCF_PROB_CROSS2D ? duo_bwd_fn<2>() : duo_bwd_fn<3>();
+    const void* fk = pb.kind == NOCF_PROB_CROSS2D ? (dw ? duo_bwd_fn<2, true>() : duo_bwd_fn<2, false>()) : (dw ? duo_bwd_fn<3, true>() : duo_bwd_fn<3, false>());
     int dev = 0, cus = 0, perCU = 0;
     if (hipGetDevice(&dev) || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) return 1;
     const size_t ldsBytes0 = (size_t)dp0.ldsFloats * 4;
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024));
     if (e) return (int)e;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fk, 256, ldsBytes0) != hipSuccess) return 1;
-    const int grid0 = 128 * ((dp0.ngroups + 7) / 8);
+    const int wpg = dw ? 32 : 16;
+    const int grid0 = 8 * wpg * ((dp0.ngroups + 7) / 8);
     if ((long)perCU * cus < grid0) {
         if (debug) fprintf(stderr, "[nocf] duo adjoint kernel: grid %d does not fit (%d workgroups per CU x %d CUs)\n", grid0, perCU, cus);
         return 1;
@@ -1336,7 +1343,7 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
     for (long r0 = 0; r0 < h.n; r0 += chunk) {
         const long cn = std::min<long>(chunk, h.n - r0);
         DuoPlan dp;
-        int rc = make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cn, &dp, true);
+        int rc = make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cn, &dp, true, dw);
         if (rc) return rc;
         dp.cb = phi->cb;
         dp.fast = du_env_int("NOCF_DUO_FAST", 1);
@@ -1352,6 +1359,8 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
         ba.a0 = h.a0; ba.a3 = h.a3; ba.a4 = h.a4; ba.a5 = h.a5; ba.inv_n = h.inv_n;
         ba.Y = h.Y; ba.Ab = h.Ab; ba.Wb = h.Wb; ba.Qb = h.Qb; ba.Ob = h.Ob; ba.Gb = h.Gb; ba.lam0 = h.lam0;
         ba.stamps = h.stamps;
+        ba.dK1p = dw ? h.dw_scratch : nullptr;
+        ba.dK0p = dw ? h.dw_scratch + (size_t)2 * 16 * 512 * 512 : nullptr;
         DuoRun rr{r0, h.n};
         const DuoPlan* dpp = reinterpret_cast<const DuoPlan*>(ws + dp.oPlan);
         const size_t ldsBytes = (size_t)dp.ldsFloats * 4;
@@ -1359,10 +1368,18 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
                            r0, r0 + cn, dp.ngroups, dp.NT, ldsBytes, perCU);
         void* args[] = {(void*)&dpp, (void*)&pb, (void*)&ws, (void*)&ba, (void*)&rr};
         if (ev0 && r0 == 0) (void)hipEventRecord(ev0, st);
-        e = hipLaunchKernel(fk, dim3(128 * ((dp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st);
+        e = hipLaunchKernel(fk, dim3(8 * wpg * ((dp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st);
         if (e) return (int)e;
+        if (dw) {                                                  // the groups' partial sums of this launch -> dK1 / dK0 (fixed order)
+            hipLaunchKernelGGL(duo_dw_reduce_kernel, dim3(1024), dim3(256), 0, st, ba.dK1p, ba.dK0p, dp.ngroups, phi->d + 1, h.dK1, h.dK0, r0 > 0 ? 1 : 0);
+            e = hipGetLastError();
+            if (e) return (int)e;
+        }
         if (ev1 && r0 + chunk >= h.n) (void)hipEventRecord(ev1, st);
     }
+    if (h.dw_done) *h.dw_done = dw ? 1 : 0;
     *errp = reinterpret_cast<const unsigned*>(ws) + dp0.oErr;
     return 0;
 }
+
+size_t duo_dw_scratch_floats(void) { return (size_t)2 * 16 * 512 * (512 + DU_DP); }

@@ -2141,11 +2141,22 @@ int nocf_poison_if_failed_f32(float* buf, int64_t count, void* stream) {
     return (int)hipGetLastError();
 }
 
+size_t nocf_dw_scratch_floats(void) {
+#ifdef NOCF_JIT_ONLY
+    return 0;
+#else
+    return duo_dw_scratch_floats();
+#endif
+}
+
 int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
                               const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
                               const float* tape, float* Y, float* Ab, float* Wb, float* Qb, float* Ob, float* Gb, float* lam0,
+                              float* dK1, float* dK0, float* dw_scratch, size_t dw_scratch_floats, int32_t* dw_done,
                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (dw_done) *dw_done = 0;
 #ifdef NOCF_JIT_ONLY
+    (void)dK1; (void)dK0; (void)dw_scratch; (void)dw_scratch_floats;
     (void)phi; (void)prob; (void)n; (void)nt; (void)stepper; (void)alph; (void)inv_n; (void)s_all; (void)z_final; (void)hs; (void)tape;
     (void)Y; (void)Ab; (void)Wb; (void)Qb; (void)Ob; (void)Gb; (void)lam0; (void)workspace; (void)workspace_bytes; (void)stream;
     return NOCF_E_SHAPE;
@@ -2165,6 +2176,7 @@ int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t 
     h.n = n; h.nt = nt; h.stepper = stepper;
     h.a0 = alph[0]; h.a3 = alph[3]; h.a4 = alph[4]; h.a5 = alph[5]; h.inv_n = (float)inv_n;
     h.Y = Y; h.Ab = Ab; h.Wb = Wb; h.Qb = Qb; h.Ob = Ob; h.Gb = Gb; h.lam0 = lam0;
+    h.dK1 = dK1; h.dK0 = dK0; h.dw_scratch = dw_scratch; h.dw_scratch_floats = dw_scratch_floats; h.dw_done = dw_done;
     h.stamps = g_stamp_buf;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_prof_on) { if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown; }

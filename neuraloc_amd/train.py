@@ -279,11 +279,19 @@ class _OCflowTrain(torch.autograd.Function):
         Y, Ab, Wb, Qb, Ob = (torch.empty(R, m, device=dev) for _ in range(5))
         Gb = torch.empty(R, D1, device=dev)
         lib = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+        # the two large weight gradients are accumulated in the kernel (weight-gradient roles, nocf_duo_bwd.inc); NOCF_DUO_DW=0: contracted below
+        dK1, dK0 = torch.empty(m, m, device=dev), torch.empty(m, D1, device=dev)
+        nsc = int(lib.nocf_dw_scratch_floats())
+        sc_dw = _SCRATCH.get(("dw", dev))
+        if sc_dw is None or sc_dw.numel() < nsc:
+            sc_dw = _SCRATCH[("dw", dev)] = torch.empty(max(nsc, 1), device=dev)
+        dw_done = C.c_int32(0)
         with torch.cuda.device(dev):
             rc = lib.nocf_rollout_bwd_tape_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper], alph_c,
                                                1.0 / float(ctx.n_total), _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(tape),
                                                _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Wb), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb),
-                                               _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                                               _lib.ptr(lam0), _lib.ptr(dK1), _lib.ptr(dK0), _lib.ptr(sc_dw), sc_dw.numel(), C.byref(dw_done),
+                                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         if rc == -2:
             return None
         _lib.check(rc, "nocf_rollout_bwd_tape_f32")
@@ -301,8 +309,12 @@ class _OCflowTrain(torch.autograd.Function):
         Qb[R - n:].addcmul_(TH1[R - n:] * w.t(), phib[:, None])
         Ob[R - n:].addcmul_(Y[R - n:], phib[:, None])
         Wb[R - n:].addcmul_(u1, phib[:, None])
-        grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": _colsum(Ob),
-                 "N.layers.1.weight": _contract(Qb, U0, w * _contract(TH1, Ab)), "N.layers.1.bias": _colsum(Qb),
+        if dw_done.value:                                         # (the kernel's sums include the value's rows)
+            gK0, gK1 = dK0, dK1
+        else:
+            gK0, gK1 = _contract(Ob, Sx, _contract(Y, Gb)), _contract(Qb, U0, w * _contract(TH1, Ab))
+        grads = {"N.layers.0.weight": gK0, "N.layers.0.bias": _colsum(Ob),
+                 "N.layers.1.weight": gK1, "N.layers.1.bias": _colsum(Qb),
                  "w.weight": _colsum(Wb).reshape(1, -1),
                  "c.weight": (_colsum(Gb) + phib @ sT).reshape(1, -1), "c.bias": phib.sum().reshape(1)}
         dM = _contract(Gb, Sx) + 0.5 * (sT * phib[:, None]).t() @ sT

@@ -52,8 +52,10 @@ def test_double_precision_and_column_sum_entries_check_their_arguments(L):
     """nocf_rollout_f64 / nocf_phi_f64 / nocf_prob_eval_f64 / nocf_colsum_f32 return codes for bad arguments (nothing is launched)"""
     for n in ("nocf_rollout_f64", "nocf_phi_f64", "nocf_prob_eval_f64", "nocf_workspace_bytes_f64", "nocf_colsum_f32"):
         assert hasattr(L, n), n
-    # workspace: K0^T image + (nTh-1) transposed layers, doubles
-    assert L.nocf_workspace_bytes_f64(150, 512, 2) == ((150 + 1) * 512 + 512 * 512) * 8
+    # workspace: K0^T image + (nTh-1) transposed layers + the packed operand images of the matrix-pipe products (opening 512 x 151:
+    # 4 waves x 38 k-steps x 8 groups x 64; two 512 x 512 layer images; closing 151 x 512: 4 x 128 x 4 x 64), doubles
+    imgs = 4 * 38 * 8 * 64 + 2 * (4 * 128 * 8 * 64) + 4 * 128 * 4 * 64
+    assert L.nocf_workspace_bytes_f64(150, 512, 2) == ((150 + 1) * 512 + 512 * 512 + imgs) * 8
     assert L.nocf_workspace_bytes_f64(4, 32, 1) == 0
     phi, prob = _lib.NocfPhi64(), _lib.NocfProb64()
     alph = (C.c_double * 6)(*[1.0] * 6)

@@ -93,8 +93,13 @@ def main():
     Y, Ab, Wb, Qb, Ob = (torch.full((R, m), float("nan"), device=dev) for _ in range(5))
     Gb = torch.full((R, D1), float("nan"), device=dev)
     lam0 = torch.full((n, d), float("nan"), device=dev)
+    dK1, dK0 = torch.full((m, m), float("nan"), device=dev), torch.full((m, D1), float("nan"), device=dev)
+    sc_dw = torch.full((int(L.nocf_dw_scratch_floats()),), float("nan"), device=dev)
+    dwd = C.c_int32(0)
     rc = L.nocf_rollout_bwd_tape_f32(C.byref(phi_st), C.byref(prob_st), n, nt, st, alph_c, inv_n, _lib.ptr(s_all), _lib.ptr(z), _lib.ptr(hs), _lib.ptr(tape),
-                                     _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Wb), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), sp)
+                                     _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Wb), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb), _lib.ptr(lam0),
+                                     _lib.ptr(dK1), _lib.ptr(dK0), _lib.ptr(sc_dw), sc_dw.numel(), C.byref(dwd), _lib.ptr(ws), ws.numel(), sp)
+    print("weight-gradient roles ran:", dwd.value)
     print("nocf_rollout_bwd_tape_f32 rc", rc)
     _lib.check(rc, "bwd tape")
     torch.cuda.synchronize()
@@ -107,6 +112,34 @@ def main():
     Qb[R - n:] += phib[:, None] * (tape[2 * R * m:3 * R * m].view(R, m)[R - n:] * wv)
     Ob[R - n:] += phib[:, None] * Y[R - n:]
     Wb[R - n:] += phib[:, None] * u1
+    if dwd.value and os.environ.get("DBG_DW"):
+        ng = min(16, (n + 15) // 16)
+        p1 = sc_dw[:2 * 16 * 512 * 512].view(32, 512, 512)
+        p0 = sc_dw[2 * 16 * 512 * 512:].view(32, 512, 160)
+        for g_ in range(2 * ng):
+            a_, b_ = p1[g_], p0[g_]
+            wr = torch.nonzero(~torch.isnan(a_).any(dim=1)).flatten().tolist()
+            print(f"    rows written (dK1): {wr[:10]}{'...' if len(wr) > 10 else ''} count {len(wr)}; dK0 nonzero rows {torch.nonzero(torch.nan_to_num(b_).abs().amax(dim=1) > 0).flatten().tolist()[:12]}")
+            print(f"  partial slab {g_} (group {g_ // 2}, C{g_ % 2 + 1}): dK1 nan rows {int(torch.isnan(a_).any(dim=1).sum())}/512 absmax {float(torch.nan_to_num(a_).abs().max()):.3e};"
+                  f" dK0 nan rows {int(torch.isnan(b_).any(dim=1).sum())}/512 absmax {float(torch.nan_to_num(b_).abs().max()):.3e}")
+    if dwd.value and os.environ.get("DBG_DW"):
+        ng = min(16, (n + 15) // 16)
+        p1 = sc_dw[:2 * 16 * 512 * 512].view(16, 2, 512, 512)[:ng].double().sum(0)
+        p0 = sc_dw[2 * 16 * 512 * 512:].view(16, 2, 512, 160)[:ng].double().sum(0)[:, :, :D1]
+        TH1_ = tape[2 * R * m:3 * R * m].view(R, m).double(); U0_ = tape[:R * m].view(R, m).double(); Sx_ = s_all.view(R, D1).double()
+        TH0_ = tape[R * m:2 * R * m].view(R, m).double(); A_ = tape[3 * R * m:4 * R * m].view(R, m).double()
+        w1 = (TH1_ * wv.double()).t() @ Ab.double(); w2 = Qb.double().t() @ U0_
+        w3 = (TH0_ * A_).t() @ Gb.double(); w4 = Ob.double().t() @ Sx_
+        for nm_, got_, want_ in (("C1 dK1 = v'abar0", p1[0], w1), ("C2 dK1 = qbar'u0 (+value rows)", p1[1], w2), ("C1 dK0 = y'gbar", p0[0], w3), ("C2 dK0 = obar's (+value rows)", p0[1], w4)):
+            dlt = (torch.nan_to_num(got_, nan=1e30) - want_).abs()
+            print(f"  {nm_}: rel {float(dlt.max() / want_.abs().max()):.3e}  (want absmax {float(want_.abs().max()):.3e}, got absmax {float(torch.nan_to_num(got_).abs().max()):.3e}, nan entries {int(torch.isnan(got_).sum())})")
+    if dwd.value:
+        TH1_ = tape[2 * R * m:3 * R * m].view(R, m); U0_ = tape[:R * m].view(R, m); Sx_ = s_all.view(R, D1)
+        wantK1 = (Qb.double().t() @ U0_.double()) + wv.double().t() * (TH1_.double().t() @ Ab.double())
+        wantK0 = (Ob.double().t() @ Sx_.double()) + (Y.double().t() @ Gb.double())
+        print("  in-kernel dK1 vs contraction of the streams (fp64): rel %.3e   dK0: rel %.3e   finite %s" % (
+            float((dK1.double() - wantK1).abs().max() / wantK1.abs().max()), float((dK0.double() - wantK0).abs().max() / wantK0.abs().max()),
+            bool(torch.isfinite(dK1).all() and torch.isfinite(dK0).all())))
     # old adjoint
     rows = (total + 2) * n
     oY, oOb, oWb = (torch.zeros(rows, m, device=dev) for _ in range(3))
