@@ -1319,7 +1319,7 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
     if (pb.kind == NOCF_PROB_QUADCOPTER) return 1;
     // dw: the kernel with the two weight-gradient roles (dK1 / dK0 accumulated in the kernel): 32 workgroups per group, 16 groups,
     // 1024 rows per launch
-    const bool dw = h.dK1 != nullptr && h.dK0 != nullptr && h.dw_scratch != nullptr && du_env_int("NOCF_DUO_DW", 1) != 0 &&
+    const bool dw = h.dK1 != nullptr && h.dK0 != nullptr && h.dw_scratch != nullptr && du_env_int("NOCF_DUO_DW", 0) != 0 &&
                     h.dw_scratch_floats >= duo_dw_scratch_floats();
     const long chunk = dw ? duo_rows_per_launch() / 2 : duo_rows_per_launch();
     DuoPlan dp0;

@@ -311,6 +311,15 @@ class _OCflowTrain(torch.autograd.Function):
         Wb[R - n:].addcmul_(u1, phib[:, None])
         if dw_done.value:                                         # (the kernel's sums include the value's rows)
             gK0, gK1 = dK0, dK1
+            if os.environ.get("NOCF_DW_CHECK"):                   # diagnostic: the kernel's sums against the contraction of the streams
+                cK0, cK1 = _contract(Ob, Sx, _contract(Y, Gb)), _contract(Qb, U0, w * _contract(TH1, Ab))
+                p0 = sc_dw[2 * 16 * 512 * 512:].view(16, 2, 512, 160)
+                ng = min(16, (min(n, 1024) + 15) // 16)
+                c1 = p0[:ng, 0].sum(0)[:, :D1]; c2 = p0[:ng, 1].sum(0)[:, :D1]
+                w1, w2 = _contract(Y, Gb), _contract(Ob, Sx)
+                print(f"[dw check] dK0 rel {float((dK0 - cK0).abs().max() / cK0.abs().max()):.2e} dK1 rel {float((dK1 - cK1).abs().max() / cK1.abs().max()):.2e}"
+                      f" | C1 y'gbar rel {float((c1 - w1).abs().max() / w1.abs().max()):.2e} C2 obar's rel {float((c2 - w2).abs().max() / w2.abs().max()):.2e}"
+                      f" | bad cols C1 {sorted(set(torch.nonzero((c1 - w1).abs() > 1e-3 * w1.abs().max())[:, 1].tolist()))[:12]} C2 {sorted(set(torch.nonzero((c2 - w2).abs() > 1e-3 * w2.abs().max())[:, 1].tolist()))[:12]}")
         else:
             gK0, gK1 = _contract(Ob, Sx, _contract(Y, Gb)), _contract(Qb, U0, w * _contract(TH1, Ab))
         grads = {"N.layers.0.weight": gK0, "N.layers.0.bias": _colsum(Ob),
