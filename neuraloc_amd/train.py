@@ -279,7 +279,8 @@ class _OCflowTrain(torch.autograd.Function):
         Y, Ab, Wb, Qb, Ob = (torch.empty(R, m, device=dev) for _ in range(5))
         Gb = torch.empty(R, D1, device=dev)
         lib = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
-        # the two large weight gradients are accumulated in the kernel (weight-gradient roles, nocf_duo_bwd.inc); NOCF_DUO_DW=0: contracted below
+        # NOCF_DUO_DW=1: the two large weight gradients are accumulated in the kernel (weight-gradient roles, nocf_duo_bwd.inc); measured
+        # slower than contracting the streams afterwards, so the default contracts them below
         dK1, dK0 = torch.empty(m, m, device=dev), torch.empty(m, D1, device=dev)
         nsc = int(lib.nocf_dw_scratch_floats())
         sc_dw = _SCRATCH.get(("dw", dev))
@@ -311,15 +312,6 @@ class _OCflowTrain(torch.autograd.Function):
         Wb[R - n:].addcmul_(u1, phib[:, None])
         if dw_done.value:                                         # (the kernel's sums include the value's rows)
             gK0, gK1 = dK0, dK1
-            if os.environ.get("NOCF_DW_CHECK"):                   # diagnostic: the kernel's sums against the contraction of the streams
-                cK0, cK1 = _contract(Ob, Sx, _contract(Y, Gb)), _contract(Qb, U0, w * _contract(TH1, Ab))
-                p0 = sc_dw[2 * 16 * 512 * 512:].view(16, 2, 512, 160)
-                ng = min(16, (min(n, 1024) + 15) // 16)
-                c1 = p0[:ng, 0].sum(0)[:, :D1]; c2 = p0[:ng, 1].sum(0)[:, :D1]
-                w1, w2 = _contract(Y, Gb), _contract(Ob, Sx)
-                print(f"[dw check] dK0 rel {float((dK0 - cK0).abs().max() / cK0.abs().max()):.2e} dK1 rel {float((dK1 - cK1).abs().max() / cK1.abs().max()):.2e}"
-                      f" | C1 y'gbar rel {float((c1 - w1).abs().max() / w1.abs().max()):.2e} C2 obar's rel {float((c2 - w2).abs().max() / w2.abs().max()):.2e}"
-                      f" | bad cols C1 {sorted(set(torch.nonzero((c1 - w1).abs() > 1e-3 * w1.abs().max())[:, 1].tolist()))[:12]} C2 {sorted(set(torch.nonzero((c2 - w2).abs() > 1e-3 * w2.abs().max())[:, 1].tolist()))[:12]}")
         else:
             gK0, gK1 = _contract(Ob, Sx, _contract(Y, Gb)), _contract(Qb, U0, w * _contract(TH1, Ab))
         grads = {"N.layers.0.weight": gK0, "N.layers.0.bias": _colsum(Ob),
