@@ -1522,6 +1522,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
 #include "nocf_lane_bwd.inc"
+#include "nocf_mono_bwd.inc"
 
 // ------------------------------------------------------------------------------------------
 // host side: plan construction and the C ABI
@@ -1556,7 +1557,7 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, i
 
 // Mono (one-CU weight-stationary) plan: returns 0 and fills *out when the shape has an instantiation, else an NOCF_E_* code.
 #define MONO_SHAPES(X) X(8, 1) X(4, 1) X(2, 1)
-static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out) {
+static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out, bool bwd = false) {
     if (base.nTh != 2 || base.r > 16) return NOCF_E_SHAPE;
     const int KBD = cdiv(base.D1, 16);
     int KBM = cdiv(base.m, 16);
@@ -1595,8 +1596,12 @@ static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out) {
     pl.lTRIG = take(T * std::max(1, n_agents) * 6);
     pl.lPT = take(4);
     pl.lPW = take(4);
+    if (bwd) {                                                 // nocf_mono_bwd.inc: its LDS layout is a compile-time constant of the kernel
+        if (KBD != 1 || base.LDs != MONO_BWD_LDS_S || base.GLD != MONO_BWD_GLD || base.ZLD > MONO_BWD_ZLD || n_agents > MONO_BWD_NAG) return NOCF_E_SHAPE;
+        l = mono_bwd_lds(KBM).total;
+    }
     pl.ldsFloats = l;
-    if ((size_t)l * 4 > 64 * 1024) return NOCF_E_LDS;
+    if ((size_t)l * 4 > (bwd ? 160 : 64) * 1024) return NOCF_E_LDS;
     long o = base.oPlan + (long)rup((int)(sizeof(MonoPlan) / 4), 64);         // floats
     const long nW = (long)KBM * KBM * 64, nK1 = (long)KBM * KBD * 64, nK4 = (long)KBD * KBM * 64, nA = (long)KBD * 64;   // float4s
     mp.oW2 = o / 4; o += nW * 4;
@@ -2242,6 +2247,7 @@ static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n,
     ba.PHIb = PHIb; ba.lam0 = lam0;
     ba.act = (act_rec && phi->nTh == 2) ? act_rec : nullptr; ba.actRows = (long)nt * ba.nstage * n;
     ba.lstride = ((long)nt * ba.nstage + 2) * n * phi->m;
+    ba.gpart = nullptr; ba.gstride = 0;
     const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
     const void* fk = nullptr;
     if (env_int("NOCF_FIXED", 1)) {
@@ -2269,6 +2275,84 @@ static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n,
         g_last_errp = nullptr;
     }
     return (int)hipGetLastError();
+}
+
+// ---- the adjoint on the one-CU weight-stationary layout (nocf_mono_bwd.inc): medium two-layer networks, every problem class
+int64_t nocf_mid_grad_rows(int32_t d, int32_t m, int32_t nTh, int32_t r, int32_t n_agents, int64_t n) {
+#ifdef NOCF_JIT_ONLY
+    (void)d; (void)m; (void)nTh; (void)r; (void)n_agents; (void)n;
+    return 0;
+#else
+    if (env_int("NOCF_MONO", 1) == 0 || env_int("NOCF_MONO_BWD", 1) == 0 || n < 1 || m <= 32) return 0;
+    DevPlan pl;
+    if (make_plan(d, m, nTh, r, n_agents, &pl, 0)) return 0;
+    MonoPlan mpl;
+    if (make_mono_plan(pl, n_agents, &mpl, true)) return 0;
+    if (!((mpl.KBM == 8 || mpl.KBM == 4) && mpl.KBD == 1)) return 0;
+    return (n + 15) / 16;
+#endif
+}
+
+int nocf_rollout_bwd_mid_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                             const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                             float* gpart, int64_t gpart_rows, float* lam0, void* workspace, size_t workspace_bytes, void* stream) {
+#ifdef NOCF_JIT_ONLY
+    (void)phi; (void)prob; (void)n; (void)nt; (void)stepper; (void)t1; (void)alph; (void)inv_n; (void)s_all; (void)z_final; (void)hs;
+    (void)gpart; (void)gpart_rows; (void)lam0; (void)workspace; (void)workspace_bytes; (void)stream;
+    return NOCF_E_SHAPE;
+#else
+    int rc = check_phi(phi);
+    if (rc) return rc;
+    if (!alph || !s_all || !z_final || !hs || !gpart || !workspace) return NOCF_E_NULL;
+    if (n < 1 || nt < 1) return NOCF_E_SHAPE;
+    if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
+    DevProb pb;
+    rc = fill_prob(prob, phi->d, &pb);
+    if (rc) return rc;
+    const int64_t rows = nocf_mid_grad_rows(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, n);
+    if (rows == 0) return NOCF_E_SHAPE;
+    if (gpart_rows < rows) return NOCF_E_WORKSPACE;
+    DevPlan pl;
+    rc = make_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, &pl, 0);
+    if (rc) return rc;
+    pl.cb = phi->cb;
+    MonoPlan mpl;
+    rc = make_mono_plan(pl, pb.nAgents, &mpl, true);
+    if (rc) return rc;
+    if (workspace_bytes < mono_ws_bytes(mpl)) return NOCF_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    rc = pack_weights(mpl.pp, phi, ws, st);                    // the padded vectors and the copy of A sit in front of the plan record
+    if (rc) return rc;
+    DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
+    hipLaunchKernelGGL(mono_pack_kernel, dim3(64), dim3(256), 0, st, mpl, P, ws);
+    BwdArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.sAll = s_all; ba.zT = z_final; ba.hs = hs; ba.n = n; ba.nt = nt; ba.nstage = (stepper == NOCF_RK4) ? 4 : 1;
+    ba.t1 = (float)t1;
+    ba.a0 = alph[0]; ba.a3 = alph[3]; ba.a4 = alph[4]; ba.a5 = alph[5]; ba.inv_n = (float)inv_n;
+    ba.lam0 = lam0;
+    ba.gpart = gpart; ba.gstride = nocf_small_grad_floats(phi->d, phi->m);
+    const size_t ldsBytes = (size_t)mpl.pp.ldsFloats * 4;
+    const void* fk = (mpl.KBM == 8) ? reinterpret_cast<const void*>(rollout_mono_bwd_kernel<8, 1>) : reinterpret_cast<const void*>(rollout_mono_bwd_kernel<4, 1>);
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e) return (int)e;
+    if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] mono adjoint kernel: %d hidden k-blocks, LDS %zu B/workgroup\n", mpl.KBM, ldsBytes);
+    const MonoPlan* mpp = reinterpret_cast<const MonoPlan*>(ws + mpl.pp.oPlan);
+    const float* wsc = ws;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_prof_on) {
+        if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
+        (void)hipEventRecord(ev0, st);
+    }
+    void* args[] = {(void*)&mpp, (void*)&pb, (void*)&wsc, (void*)&ba};
+    e = hipLaunchKernel(fk, dim3((unsigned)rows), dim3(256), args, ldsBytes, st);
+    if (e) return (int)e;
+    if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
+    g_last_kernel = "rollout_mono_bwd_kernel";
+    g_last_errp = nullptr;
+    return (int)hipGetLastError();
+#endif
 }
 
 static int phi_common(const NocfPhi* phi, const float* s, int64_t n, float* grad, float* value,

@@ -74,6 +74,25 @@ def _colsum(X):
     return out
 
 
+def _unpack_partials(gpart, m, D1, net):
+    """partial gradient vectors [rows, nocf_small_grad_floats] (per sample: lane adjoint; per workgroup: one-CU adjoint) -> the gradients by
+    parameter name; the rows are added in a fixed order"""
+    gv = gpart.sum(0)
+    o = 0
+    grads = {}
+    for name, shape in (("N.layers.0.weight", (m, D1)), ("N.layers.0.bias", (m,)), ("N.layers.1.weight", (m, m)),
+                        ("N.layers.1.bias", (m,)), ("w.weight", (1, m)), ("c.weight", (1, D1)), ("c.bias", (1,)),
+                        ("dM", (D1, D1))):
+        cnt = 1
+        for v_ in shape:
+            cnt *= v_
+        grads[name] = gv[o:o + cnt].reshape(shape)
+        o += cnt
+    dM = grads.pop("dM")
+    grads["A"] = net.A.detach() @ (dM + dM.t())
+    return grads
+
+
 class _OCflowTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
@@ -109,6 +128,7 @@ class _OCflowTrain(torch.autograd.Function):
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         _lib.check_errors()
         ctx.tape = None
+        ctx.mid_rows = 0
         with torch.cuda.device(dev):
             L = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
             # Training tape (wide two-layer networks on the split-role kernel): the recording forward keeps what autograd would keep of the
@@ -142,7 +162,10 @@ class _OCflowTrain(torch.autograd.Function):
             # activation record (wide two-layer networks on the split-role kernel): the forward keeps u0, tanh(o), tanh(q), a and grad Phi
             # of every evaluation -- autograd's saved tensors, 2.9 GB for swarm50 -- and the adjoint loads them instead of re-running
             # grad Phi's forward sweep (NOCF_ACT_REC=0: recompute, as for every other shape)
-            nact = 0 if os.environ.get("NOCF_ACT_REC", "1") in ("0", "") else int(
+            # (medium networks on the one-CU adjoint re-run grad Phi from registers: no record)
+            ctx.mid_rows = int(L.nocf_mid_grad_rows(int(d), int(net.m), int(net.nTh), int(phi_st.r), int(prob_st.n_agents), int(n))) \
+                if hasattr(L, "nocf_rollout_bwd_mid_f32") else 0
+            nact = 0 if (ctx.mid_rows or os.environ.get("NOCF_ACT_REC", "1") in ("0", "")) else int(
                 L.nocf_activation_record_floats(int(d), int(net.m), int(net.nTh), int(n), int(nt), _STEPPERS[stepper]))
             act = None
             if nact:
@@ -215,22 +238,22 @@ class _OCflowTrain(torch.autograd.Function):
                                                     _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(gpart), _lib.ptr(lam0),
                                                     _lib.stream_ptr(dev))
             if rc == 0:
-                gv = gpart.sum(0)
-                o = 0
-                grads = {}
-                for name, shape in (("N.layers.0.weight", (m, D1)), ("N.layers.0.bias", (m,)), ("N.layers.1.weight", (m, m)),
-                                    ("N.layers.1.bias", (m,)), ("w.weight", (1, m)), ("c.weight", (1, D1)), ("c.bias", (1,)),
-                                    ("dM", (D1, D1))):
-                    cnt = 1
-                    for v_ in shape:
-                        cnt *= v_
-                    grads[name] = gv[o:o + cnt].reshape(shape)
-                    o += cnt
-                dM = grads.pop("dM")
-                grads["A"] = net.A.detach() @ (dM + dM.t())
-                return _OCflowTrain._finish(ctx, gJ, grads, lam0, net)
+                return _OCflowTrain._finish(ctx, gJ, _unpack_partials(gpart, m, D1, net), lam0, net)
             if rc != -2:                                               # NOCF_E_SHAPE: not a lane-kernel shape -> row streams below
                 _lib.check(rc, "nocf_rollout_bwd_small_f32")
+        # medium two-layer networks: the one-CU adjoint accumulates the weight gradients in the kernel (one partial vector per workgroup)
+        mid_rows = int(getattr(ctx, "mid_rows", 0))
+        if mid_rows:
+            gmid = torch.empty(mid_rows, P, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.nocf_rollout_bwd_mid_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
+                                                  float(ctx.tspan[1]), alph_c, 1.0 / float(ctx.n_total), _lib.ptr(s_all),
+                                                  _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(gmid), mid_rows, _lib.ptr(lam0),
+                                                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            if rc == 0:
+                return _OCflowTrain._finish(ctx, gJ, _unpack_partials(gmid, m, D1, net), lam0, net)
+            if rc != -2:
+                _lib.check(rc, "nocf_rollout_bwd_mid_f32")
         L = net.nTh - 1
         # every row the kernel does not write must be zero: the value block (last n rows) of Y / V / Ab / Gb
         Y, Ob, Wb = (torch.empty(rows, m, device=dev) for _ in range(3))

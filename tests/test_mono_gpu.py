@@ -113,19 +113,21 @@ def test_mono_other_widths_against_oracle(m_, training):
     assert _flips(got, want) == 0, f"m={m_}: {_flips(got, want)} samples off"
 
 
-@pytest.mark.parametrize("n,nt,stepper", [(37, 5, "rk4"), (4096, 3, "rk4"), (100, 6, "rk1")])
-def test_mono_training_forward_records_and_the_activation_record_matches_the_recomputing_adjoint(n, nt, stepper, monkeypatch):
-    """training of singlequad: the one-CU kernel is the recording forward (stage inputs), and with the activation record
-    (NOCF_ACT_REC, default on) it also keeps u0, tanh(o), tanh(q), a and grad Phi so that the adjoint does not re-run grad Phi's
-    forward sweep.  Same forward either way (Jc identical); gradients equal up to the rounding of the two forward sweeps; the
-    recording forward on the tile kernel (NOCF_MONO_REC=0) agrees too."""
+@pytest.mark.parametrize("n,nt,stepper", [(37, 5, "rk4"), (4096, 3, "rk4"), (100, 6, "rk1"), (1, 4, "rk4"), (16, 2, "rk1")])
+def test_mono_adjoint_against_both_per_tile_adjoints(n, nt, stepper, monkeypatch):
+    """training of singlequad: the one-CU kernel is the recording forward (stage inputs) and the one-CU adjoint (nocf_mono_bwd.inc: grad Phi
+    re-run from registers, weight gradients accumulated in the kernel, one partial vector per workgroup) is the backward.  Against the
+    per-tile adjoint with the activation record (NOCF_MONO_BWD=0), recomputing (NOCF_ACT_REC=0 too) and behind the tile kernel's recording
+    forward (NOCF_MONO_REC=0): same Jc from the same forward, gradients and dJc/dx0 equal up to the rounding of the forward sweeps."""
     from neuraloc_amd import _lib
     g = load_golden("singlequad")
     m = g.meta
     x = (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 7)).contiguous().to(DEV)
     out = {}
-    for tag, env in (("rec", {"NOCF_ACT_REC": "1"}), ("norec", {"NOCF_ACT_REC": "0"}), ("tile", {"NOCF_ACT_REC": "0", "NOCF_MONO_REC": "0"})):
-        for k_ in ("NOCF_ACT_REC", "NOCF_MONO_REC"):
+    knobs = ("NOCF_ACT_REC", "NOCF_MONO_REC", "NOCF_MONO_BWD")
+    for tag, env in (("mid", {}), ("rec", {"NOCF_MONO_BWD": "0"}), ("norec", {"NOCF_MONO_BWD": "0", "NOCF_ACT_REC": "0"}),
+                     ("tile", {"NOCF_MONO_BWD": "0", "NOCF_ACT_REC": "0", "NOCF_MONO_REC": "0"})):
+        for k_ in knobs:
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
@@ -137,11 +139,48 @@ def test_mono_training_forward_records_and_the_activation_record_matches_the_rec
         assert kern == ("rollout_mono_kernel" if tag != "tile" else "rollout_kernel<shape-specialised>"), kern
         Jc.backward()
         torch.cuda.synchronize()
+        kern = _lib.lib().nocf_last_rollout_kernel().decode()
+        assert kern == ("rollout_mono_bwd_kernel" if tag == "mid" else "rollout_bwd_kernel"), kern
         out[tag] = (float(Jc.detach()), [p.grad.detach().clone() for p in net.parameters()], xx.grad.detach().clone())
-    assert out["rec"][0] == out["norec"][0]
-    assert abs(out["rec"][0] - out["tile"][0]) <= 2e-5 * abs(out["tile"][0])
-    for other, tol in (("norec", 2e-4), ("tile", 2e-3)):
-        for ga, gb in zip(out["rec"][1], out[other][1]):
+    assert out["mid"][0] == out["rec"][0] == out["norec"][0]
+    assert abs(out["mid"][0] - out["tile"][0]) <= 2e-5 * abs(out["tile"][0])
+    for other, tol in (("rec", 5e-4), ("norec", 5e-4), ("tile", 2e-3)):
+        for ga, gb in zip(out["mid"][1], out[other][1]):
             scale = float(gb.abs().max())
             assert torch.isfinite(ga).all() and float((ga - gb).abs().max()) <= tol * scale + 1e-12, (other, float((ga - gb).abs().max()), scale)
-        assert float((out["rec"][2] - out[other][2]).abs().max()) <= tol * float(out[other][2].abs().max()) + 1e-12
+        assert float((out["mid"][2] - out[other][2]).abs().max()) <= tol * float(out[other][2].abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("name,n,stepper,training,m_", [
+    ("singlequad", 11, "rk4", True, 128), ("singlequad", 21, "rk1", False, 64), ("singlequad", 33, "rk4", True, 120),
+    ("midcross4", 13, "rk4", True, 128), ("midcross4", 16, "rk1", False, 64), ("softcorridor", 7, "rk4", True, 64),
+    ("midcross4", 40, "rk4", False, 128), ("swap2", 1, "rk4", True, 48), ("midcross2", 9, "rk4", False, 128)])
+def test_mono_adjoint_against_oracle_fp64_autograd(name, n, stepper, training, m_):
+    """the one-CU adjoint on medium networks of every problem class with d + 1 <= 16 (quadcopter physics; point agents with obstacle and
+    interaction terms, both mask modes), ragged batches, hidden widths that are padded: dJc/dtheta against the oracle differentiated by
+    torch autograd in fp64"""
+    from neuraloc_amd import _lib
+    from util_hip import synth_state_dict as _synth_state_dict
+    from test_hip_parity import _oracle_grads64
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(11)
+    prob, x0, _, _ = na.initProb(name, 40, 40, 0.5, alph, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    x0 = x0[:n].contiguous()
+    d = x0.shape[1]
+    sd = _synth_state_dict(2, m_, d, seed=len(name))
+    net = na.Phi(nTh=2, m=m_, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    nt = 6
+    Jc, _ = na.OCflow(x0, net, prob, [0.0, 1.0], nt, stepper, alph)
+    Jc.backward()
+    torch.cuda.synchronize()
+    assert _lib.lib().nocf_last_rollout_kernel().decode() == "rollout_mono_bwd_kernel"
+    J64, want = _oracle_grads64(x0, sd, prob, nt, stepper, alph, 2)
+    assert abs(Jc.item() - J64) <= 2e-5 * abs(J64)
+    for k, p in net.named_parameters():
+        w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()
+        scale = w.abs().max().item()
+        err = (p.grad.cpu().double() - w).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-6, f"{name} {k}: err {err:g} at scale {scale:g}"
