@@ -19,6 +19,13 @@ POINTS = {38: "eval: s loaded", 0: "phi_eval entry", 2: "open barrier", 3: "fwd 
 ORDER = [38, 0, 2, 3, 4, 5, 39, 41, 45, 46, 47, 54, 55, 56, 57, 58, 59]
 
 
+MONO_POINTS = {0: "eval start", 1: "s rows + fragments", 2: "P1 + epilogue", 3: "barrier", 4: "P2", 5: "P2 epilogue", 6: "barrier", 7: "P3 + epilogue",
+               8: "barrier", 9: "P4 partials", 10: "grad Phi rows (2 barriers)", 11: "physics sums", 12: "cotangents (physics adjoint)",
+               13: "gbar fragments + barrier", 14: "P1' + epilogue", 15: "barrier", 16: "P2'", 17: "P2' epilogue", 18: "barrier", 19: "P3'",
+               20: "P3' epilogue", 21: "barrier", 22: "P4' partials", 23: "barrier + sbar rows", 24: "outer products (dK1, dK0, dM)", 25: "barrier",
+               26: "RK recurrences + barrier"}
+
+
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "swarm50"
     meta, sd, xtarget, xInit = bench.load_workload(wl)
@@ -40,6 +47,15 @@ def main():
     Jc.backward()
     torch.cuda.synchronize()
     tl = buf.view(8, 64).cpu()
+    if _lib.lib().nocf_last_rollout_kernel().decode() == "rollout_mono_bwd_kernel":      # the one-CU adjoint (nocf_mono_bwd.inc): 4 waves
+        t0 = int(tl[:4, 0].min())
+        print(f"{'point (cycles since the start; d = since the previous point, wave 0)':70s}" + "".join(f"   wave{w}" for w in range(4)))
+        prev = 0
+        for p in range(27):
+            row = [int(tl[w, p]) - t0 for w in range(4)]
+            print(f"{MONO_POINTS[p]:58s} d {row[0] - prev:6d}  " + "".join(f"{v:8d}" for v in row))
+            prev = row[0]
+        return
     t0 = int(tl[:, 38][tl[:, 38] > 0].min())
     print(f"{'point':28s}" + "".join(f"   wave{w}" for w in range(8)))
     for p in ORDER:
