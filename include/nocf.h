@@ -271,18 +271,21 @@ int nocf_rollout_bwd_small_f32(const NocfPhi* phi, const NocfProb* prob, int64_t
 /*
  * The same adjoint for MEDIUM two-layer networks (nTh = 2, 32 < m <= 128, d+1 <= 16, every problem class: the shapes the one-CU
  * weight-stationary kernel of nocf_rollout_f32 takes, e.g. singlequad; reference: trainOC.py:172-174 on src/OCflow.py:7-140).  One
- * workgroup per 16 samples keeps the network in its registers, re-runs grad Phi at the recorded stage inputs and ACCUMULATES the
- * weight gradients in the kernel (MFMA outer products with the samples on the k axis): no row stream, no activation record, no
- * library GEMM.  Every workgroup writes one partial gradient vector; the caller adds the partial vectors (fixed order).
+ * workgroup per 16 samples keeps the network in its registers, takes grad Phi's activations from the forward's activation record
+ * (act_rec of nocf_rollout_record_act_f32, requested one evaluation ahead; null or `recorded` = 0: it re-runs grad Phi at the recorded
+ * stage inputs) and ACCUMULATES the weight gradients in the kernel (MFMA outer products with the samples on the k axis): no row
+ * stream, no library GEMM.  Every workgroup writes one partial gradient vector; the caller adds the partial vectors (fixed order).
  *   nocf_mid_grad_rows   number of partial vectors for a batch of n rows (ceil(n / 16)), or 0 when the shape has no such kernel
  *                        (NOCF_E_SHAPE from the launch then: use nocf_rollout_bwd_act_f32)
+ *   act_rec nullable: the activation record of the forward launch (only when that launch reported recorded = 1)
  *   gpart  device [gpart_rows, nocf_small_grad_floats(d, m)], the layout of nocf_rollout_bwd_small_f32
  *   lam0   device [n, d] = dJc/dx0 (nullable);   workspace: nocf_workspace_bytes (same as the forward's)
  */
 int64_t nocf_mid_grad_rows(int32_t d, int32_t m, int32_t nTh, int32_t r, int32_t n_agents, int64_t n);
 int nocf_rollout_bwd_mid_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
                              const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
-                             float* gpart, int64_t gpart_rows, float* lam0, void* workspace, size_t workspace_bytes, void* stream);
+                             const float* act_rec, float* gpart, int64_t gpart_rows, float* lam0, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /*
  * C[m, n] (+)= sum_k A[k, 0..m) (x) B[k, 0..n) for small outputs (m, n <= 512, at most 64 tiles of 64 x 64) and very many rows: the contraction of the rows that

@@ -237,8 +237,8 @@ def _bind(L):
         L.nocf_mid_grad_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]
         L.nocf_rollout_bwd_mid_f32.restype = C.c_int
         L.nocf_rollout_bwd_mid_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_int64, C.c_int32, C.c_int32, C.c_double,
-                                               fp, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                               C.c_void_p, C.c_size_t, C.c_void_p]
+                                               fp, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.nocf_contract_f32.restype = C.c_int
     L.nocf_contract_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_size_t, C.c_void_p]

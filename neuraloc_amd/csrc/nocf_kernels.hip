@@ -2295,10 +2295,11 @@ int64_t nocf_mid_grad_rows(int32_t d, int32_t m, int32_t nTh, int32_t r, int32_t
 
 int nocf_rollout_bwd_mid_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
                              const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
-                             float* gpart, int64_t gpart_rows, float* lam0, void* workspace, size_t workspace_bytes, void* stream) {
+                             const float* act_rec, float* gpart, int64_t gpart_rows, float* lam0, void* workspace, size_t workspace_bytes,
+                             void* stream) {
 #ifdef NOCF_JIT_ONLY
     (void)phi; (void)prob; (void)n; (void)nt; (void)stepper; (void)t1; (void)alph; (void)inv_n; (void)s_all; (void)z_final; (void)hs;
-    (void)gpart; (void)gpart_rows; (void)lam0; (void)workspace; (void)workspace_bytes; (void)stream;
+    (void)act_rec; (void)gpart; (void)gpart_rows; (void)lam0; (void)workspace; (void)workspace_bytes; (void)stream;
     return NOCF_E_SHAPE;
 #else
     int rc = check_phi(phi);
@@ -2333,6 +2334,7 @@ int nocf_rollout_bwd_mid_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
     ba.a0 = alph[0]; ba.a3 = alph[3]; ba.a4 = alph[4]; ba.a5 = alph[5]; ba.inv_n = (float)inv_n;
     ba.lam0 = lam0;
     ba.gpart = gpart; ba.gstride = nocf_small_grad_floats(phi->d, phi->m);
+    ba.act = (act_rec && (phi->m % 16) == 0) ? act_rec : nullptr; ba.actRows = (long)nt * ba.nstage * n;
     const size_t ldsBytes = (size_t)mpl.pp.ldsFloats * 4;
     const void* fk = (mpl.KBM == 8) ? reinterpret_cast<const void*>(rollout_mono_bwd_kernel<8, 1>) : reinterpret_cast<const void*>(rollout_mono_bwd_kernel<4, 1>);
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);

@@ -162,10 +162,9 @@ class _OCflowTrain(torch.autograd.Function):
             # activation record (wide two-layer networks on the split-role kernel): the forward keeps u0, tanh(o), tanh(q), a and grad Phi
             # of every evaluation -- autograd's saved tensors, 2.9 GB for swarm50 -- and the adjoint loads them instead of re-running
             # grad Phi's forward sweep (NOCF_ACT_REC=0: recompute, as for every other shape)
-            # (medium networks on the one-CU adjoint re-run grad Phi from registers: no record)
             ctx.mid_rows = int(L.nocf_mid_grad_rows(int(d), int(net.m), int(net.nTh), int(phi_st.r), int(prob_st.n_agents), int(n))) \
                 if hasattr(L, "nocf_rollout_bwd_mid_f32") else 0
-            nact = 0 if (ctx.mid_rows or os.environ.get("NOCF_ACT_REC", "1") in ("0", "")) else int(
+            nact = 0 if os.environ.get("NOCF_ACT_REC", "1") in ("0", "") else int(
                 L.nocf_activation_record_floats(int(d), int(net.m), int(net.nTh), int(n), int(nt), _STEPPERS[stepper]))
             act = None
             if nact:
@@ -241,16 +240,19 @@ class _OCflowTrain(torch.autograd.Function):
                 return _OCflowTrain._finish(ctx, gJ, _unpack_partials(gpart, m, D1, net), lam0, net)
             if rc != -2:                                               # NOCF_E_SHAPE: not a lane-kernel shape -> row streams below
                 _lib.check(rc, "nocf_rollout_bwd_small_f32")
-        # medium two-layer networks: the one-CU adjoint accumulates the weight gradients in the kernel (one partial vector per workgroup)
+        # medium two-layer networks: the one-CU adjoint accumulates the weight gradients in the kernel (one partial vector per workgroup);
+        # with the forward's activation record it does not re-run grad Phi's forward sweep (NOCF_ACT_REC=0: it does)
         mid_rows = int(getattr(ctx, "mid_rows", 0))
         if mid_rows:
             gmid = torch.empty(mid_rows, P, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.nocf_rollout_bwd_mid_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper],
                                                   float(ctx.tspan[1]), alph_c, 1.0 / float(ctx.n_total), _lib.ptr(s_all),
-                                                  _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(gmid), mid_rows, _lib.ptr(lam0),
+                                                  _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(getattr(ctx, "act", None)), _lib.ptr(gmid), mid_rows,
+                                                  _lib.ptr(lam0),
                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
             if rc == 0:
+                ctx.act = None
                 return _OCflowTrain._finish(ctx, gJ, _unpack_partials(gmid, m, D1, net), lam0, net)
             if rc != -2:
                 _lib.check(rc, "nocf_rollout_bwd_mid_f32")
