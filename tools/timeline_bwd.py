@@ -55,6 +55,9 @@ def main():
             row = [int(tl[w, p]) - t0 for w in range(4)]
             print(f"{MONO_POINTS[p]:58s} d {row[0] - prev:6d}  " + "".join(f"{v:8d}" for v in row))
             prev = row[0]
+        if int(tl[0, 27]) > 0:
+            a, b, c_ = (int(tl[0, q]) - t0 for q in (27, 28, 29))
+            print(f"inside the cotangents (wave 0): rows read at {a}, sin / cos back at {b}, components formed at {c_}")
         return
     t0 = int(tl[:, 38][tl[:, 38] > 0].min())
     print(f"{'point':28s}" + "".join(f"   wave{w}" for w in range(8)))
