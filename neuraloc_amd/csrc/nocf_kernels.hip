@@ -1556,7 +1556,7 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, i
 }
 
 // Mono (one-CU weight-stationary) plan: returns 0 and fills *out when the shape has an instantiation, else an NOCF_E_* code.
-#define MONO_SHAPES(X) X(8, 1) X(4, 1) X(2, 1)
+#define MONO_SHAPES(X) X(8, 1) X(4, 1) X(2, 1) X(8, 2) X(4, 2)
 static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out, bool bwd = false) {
     if (base.nTh != 2 || base.r > 16) return NOCF_E_SHAPE;
     const int KBD = cdiv(base.D1, 16);
@@ -1601,7 +1601,7 @@ static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out, bool
         l = mono_bwd_lds(KBM).total;
     }
     pl.ldsFloats = l;
-    if ((size_t)l * 4 > (bwd ? 160 : 64) * 1024) return NOCF_E_LDS;
+    if ((size_t)l * 4 > (bwd ? 160 : 96) * 1024) return NOCF_E_LDS;     // (two input k-blocks with 128 hidden units: 70 KB; one workgroup per CU either way)
     long o = base.oPlan + (long)rup((int)(sizeof(MonoPlan) / 4), 64);         // floats
     const long nW = (long)KBM * KBM * 64, nK1 = (long)KBM * KBD * 64, nK4 = (long)KBD * KBM * 64, nA = (long)KBD * 64;   // float4s
     mp.oW2 = o / 4; o += nW * 4;

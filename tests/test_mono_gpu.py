@@ -185,3 +185,26 @@ def test_mono_adjoint_against_oracle_fp64_autograd(name, n, stepper, training, m
         scale = w.abs().max().item()
         err = (p.grad.cpu().double() - w).abs().max().item()
         assert err <= 2e-4 * scale + 1e-6, f"{name} {k}: err {err:g} at scale {scale:g}"
+
+
+@pytest.mark.parametrize("name,m_,training", [("swap12", 64, True), ("swap12", 128, False), ("midcross4", 128, True), ("swap12_5pair", 48, True)])
+def test_mono_wider_inputs_against_oracle(name, m_, training, capfd, monkeypatch):
+    """medium networks on problems with 17 <= d + 1 <= 32 (two input k-blocks: 12 agents) run the one-CU kernel too; against the oracle"""
+    from util_hip import synth_state_dict as _synth_state_dict
+    monkeypatch.setenv("NOCF_DEBUG", "1")
+    alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
+    torch.manual_seed(3)
+    prob, x0, _, _ = na.initProb(name, 37, 8, 0.3, alph, lambda t: t.float().to(DEV))
+    prob.train() if training else prob.eval()
+    d = x0.shape[1]
+    sd = _synth_state_dict(2, m_, d, seed=m_ % 7)
+    net = na.Phi(nTh=2, m=m_, d=d, alph=alph)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    P = orc.PhiParams.from_state_dict(sd)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    got = _table(x0, net, prob, [0.0, 1.0], 6, "rk4", alph)
+    assert "mono kernel" in capfd.readouterr().err
+    want = orc.persample_table(x0.cpu(), P, S, [0.0, 1.0], 6, "rk4", alph)
+    assert _flips(got, want) == 0, f"{name} m={m_}: {_flips(got, want)} samples off"
