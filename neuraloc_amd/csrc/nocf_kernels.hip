@@ -1556,12 +1556,13 @@ static int make_plan(int d, int m, int nTh, int r, int n_agents, DevPlan* out, i
 }
 
 // Mono (one-CU weight-stationary) plan: returns 0 and fills *out when the shape has an instantiation, else an NOCF_E_* code.
-#define MONO_SHAPES(X) X(8, 1) X(4, 1) X(2, 1) X(8, 2) X(4, 2)
+#define MONO_SHAPES(X) X(8, 1) X(6, 1) X(4, 1) X(2, 1) X(8, 2) X(6, 2) X(4, 2)
 static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out, bool bwd = false) {
     if (base.nTh != 2 || base.r > 16) return NOCF_E_SHAPE;
     const int KBD = cdiv(base.D1, 16);
     int KBM = cdiv(base.m, 16);
-    KBM = KBM <= 2 ? 2 : (KBM <= 4 ? 4 : KBM);                 // hidden units are zero-padded up to an instantiated width
+    if (KBM > 8) return NOCF_E_SHAPE;
+    KBM = KBM <= 2 ? 2 : (KBM <= 4 ? 4 : (KBM <= 6 ? 6 : 8));   // hidden units are zero-padded up to an instantiated width (m <= 128)
     bool have = false;
 #define NOCF_MONO_HAVE(M_, D_) if (KBM == M_ && KBD == D_) have = true;
     MONO_SHAPES(NOCF_MONO_HAVE)
@@ -2288,7 +2289,7 @@ int64_t nocf_mid_grad_rows(int32_t d, int32_t m, int32_t nTh, int32_t r, int32_t
     if (make_plan(d, m, nTh, r, n_agents, &pl, 0)) return 0;
     MonoPlan mpl;
     if (make_mono_plan(pl, n_agents, &mpl, true)) return 0;
-    if (!((mpl.KBM == 8 || mpl.KBM == 4) && mpl.KBD == 1)) return 0;
+    if (!((mpl.KBM == 8 || mpl.KBM == 6 || mpl.KBM == 4) && mpl.KBD == 1)) return 0;
     return (n + 15) / 16;
 #endif
 }
@@ -2336,7 +2337,8 @@ int nocf_rollout_bwd_mid_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
     ba.gpart = gpart; ba.gstride = nocf_small_grad_floats(phi->d, phi->m);
     ba.act = (act_rec && (phi->m % 16) == 0) ? act_rec : nullptr; ba.actRows = (long)nt * ba.nstage * n;
     const size_t ldsBytes = (size_t)mpl.pp.ldsFloats * 4;
-    const void* fk = (mpl.KBM == 8) ? reinterpret_cast<const void*>(rollout_mono_bwd_kernel<8, 1>) : reinterpret_cast<const void*>(rollout_mono_bwd_kernel<4, 1>);
+    const void* fk = (mpl.KBM == 8) ? reinterpret_cast<const void*>(rollout_mono_bwd_kernel<8, 1>)
+                   : (mpl.KBM == 6) ? reinterpret_cast<const void*>(rollout_mono_bwd_kernel<6, 1>) : reinterpret_cast<const void*>(rollout_mono_bwd_kernel<4, 1>);
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e) return (int)e;
     if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] mono adjoint kernel: %d hidden k-blocks, LDS %zu B/workgroup\n", mpl.KBM, ldsBytes);

@@ -153,7 +153,8 @@ def test_mono_adjoint_against_both_per_tile_adjoints(n, nt, stepper, monkeypatch
 
 
 @pytest.mark.parametrize("name,n,stepper,training,m_", [
-    ("singlequad", 11, "rk4", True, 128), ("singlequad", 21, "rk1", False, 64), ("singlequad", 33, "rk4", True, 120),
+    ("singlequad", 11, "rk4", True, 128), ("singlequad", 21, "rk1", False, 64), ("singlequad", 33, "rk4", True, 120), ("singlequad", 17, "rk4", True, 96),
+    ("midcross4", 25, "rk4", True, 80), ("singlequad", 9, "rk4", False, 104),
     ("midcross4", 13, "rk4", True, 128), ("midcross4", 16, "rk1", False, 64), ("softcorridor", 7, "rk4", True, 64),
     ("midcross4", 40, "rk4", False, 128), ("swap2", 1, "rk4", True, 48), ("midcross2", 9, "rk4", False, 128)])
 def test_mono_adjoint_against_oracle_fp64_autograd(name, n, stepper, training, m_):
@@ -187,7 +188,7 @@ def test_mono_adjoint_against_oracle_fp64_autograd(name, n, stepper, training, m
         assert err <= 2e-4 * scale + 1e-6, f"{name} {k}: err {err:g} at scale {scale:g}"
 
 
-@pytest.mark.parametrize("name,m_,training", [("swap12", 64, True), ("swap12", 128, False), ("midcross4", 128, True), ("swap12_5pair", 48, True)])
+@pytest.mark.parametrize("name,m_,training", [("swap12", 64, True), ("swap12", 128, False), ("swap12", 96, True), ("swap12_5pair", 48, True), ("swap12_3pair", 72, False)])
 def test_mono_wider_inputs_against_oracle(name, m_, training, capfd, monkeypatch):
     """medium networks on problems with 17 <= d + 1 <= 32 (two input k-blocks: 12 agents) run the one-CU kernel too; against the oracle"""
     from util_hip import synth_state_dict as _synth_state_dict
