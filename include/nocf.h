@@ -275,7 +275,7 @@ int nocf_rollout_bwd_small_f32(const NocfPhi* phi, const NocfProb* prob, int64_t
  * (act_rec of nocf_rollout_record_act_f32, requested one evaluation ahead; null or `recorded` = 0: it re-runs grad Phi at the recorded
  * stage inputs) and ACCUMULATES the weight gradients in the kernel (MFMA outer products with the samples on the k axis): no row
  * stream, no library GEMM.  Every workgroup writes one partial gradient vector; the caller adds the partial vectors (fixed order).
- *   nocf_mid_grad_rows   number of partial vectors for a batch of n rows (ceil(n / 16)), or 0 when the shape has no such kernel
+ *   nocf_mid_grad_rows   number of partial vectors for a batch of n rows (min(ceil(n / 16), 1024)), or 0 when the shape has no such kernel
  *                        (NOCF_E_SHAPE from the launch then: use nocf_rollout_bwd_act_f32)
  *   act_rec nullable: the activation record of the forward launch (only when that launch reported recorded = 1)
  *   gpart  device [gpart_rows, nocf_small_grad_floats(d, m)], the layout of nocf_rollout_bwd_small_f32

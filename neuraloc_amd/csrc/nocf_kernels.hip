@@ -2290,7 +2290,7 @@ int64_t nocf_mid_grad_rows(int32_t d, int32_t m, int32_t nTh, int32_t r, int32_t
     MonoPlan mpl;
     if (make_mono_plan(pl, n_agents, &mpl, true)) return 0;
     if (!((mpl.KBM == 8 || mpl.KBM == 6 || mpl.KBM == 4) && mpl.KBD == 1)) return 0;
-    return (n + 15) / 16;
+    return std::min<int64_t>((n + 15) / 16, 1024);           // workgroups = partial vectors: beyond 1024 tiles a workgroup takes several
 #endif
 }
 

@@ -113,7 +113,7 @@ def test_mono_other_widths_against_oracle(m_, training):
     assert _flips(got, want) == 0, f"m={m_}: {_flips(got, want)} samples off"
 
 
-@pytest.mark.parametrize("n,nt,stepper", [(37, 5, "rk4"), (4096, 3, "rk4"), (100, 6, "rk1"), (1, 4, "rk4"), (16, 2, "rk1")])
+@pytest.mark.parametrize("n,nt,stepper", [(37, 5, "rk4"), (4096, 3, "rk4"), (100, 6, "rk1"), (1, 4, "rk4"), (16, 2, "rk1"), (20000, 2, "rk4")])
 def test_mono_adjoint_against_both_per_tile_adjoints(n, nt, stepper, monkeypatch):
     """training of singlequad: the one-CU kernel is the recording forward (stage inputs) and the one-CU adjoint (nocf_mono_bwd.inc: grad Phi
     from the activation record -- or re-run from registers, NOCF_ACT_REC=0 --, weight gradients accumulated in the kernel, one partial
