@@ -23,8 +23,6 @@ NAMES = ["opening: epilogue+barrier", "opening: z=As + weight stream (wave 0)", 
          "physics sums", "RK update/finish", "entry barrier", "-"]
 
 
-GNAMES = ["GEMM stream + partial barrier (x3)", "epilogue (x3)", "publish + wait (u0, v)", "gather + barrier", "closing stream + store",
-          "g publish + wait", "g reduce (own samples)", "physics + RK (own)", "s publish + wait", "s gather", "z = A s", "-"]
 
 
 def main():
@@ -40,8 +38,7 @@ def main():
     prob.eval()
     n, nt = meta["n_full"], meta["nt"]
     x = bench.make_states(meta, xInit, n, 200).to(dev)
-    group = os.environ.get("NOCF_GROUP", "0") != "0"
-    nwg = (n + 3) // 4 + 8 if not group else ((n + 15) // 16) * 8 + 8
+    nwg = (n + 3) // 4 + 8
     buf = torch.zeros(nwg * 12, dtype=torch.int64, device=dev)
     rc = _lib.lib().nocf_debug_set_stamp_buffer(buf.data_ptr())
     assert rc == 0, "this is not the NOCF_STAMPS build"
@@ -55,7 +52,7 @@ def main():
     tot = mean.sum().item()
     evals = 4 * nt + 1
     print(f"workload {wl}: {st.shape[0]} workgroups, {tot:.0f} cycles per workgroup, {tot / evals:.0f} per evaluation")
-    for i, nm in enumerate(GNAMES if group else NAMES):
+    for i, nm in enumerate(NAMES):
         if mean[i] > 0:
             print(f"  {nm:20s} {mean[i].item() / evals:9.0f} cyc/eval  {100 * mean[i].item() / tot:5.1f} %")
 

@@ -124,9 +124,9 @@ def main(argv=None):
         optim.zero_grad()
         Jc, cs = rollout(x0, net, prob, tspan, args.nt, "rk4", net.alph)
         Jc.backward()
-        optim.step()
         torch.cuda.synchronize()
-        na.check_errors()                                 # (after the synchronisation: a timed-out rollout raises instead of training on NaN)
+        na.check_errors()                                 # (after the synchronisation and BEFORE the step: a timed-out rollout raises, its NaN gradients are not applied)
+        optim.step()
         dt = time.time() - end
         total += dt
         line = "{:05d} {:7.1e} {:6.2f}   {:9.3e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}  {:8.2e}".format(
