@@ -1598,8 +1598,8 @@ static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out, bool
     pl.lPT = take(4);
     pl.lPW = take(4);
     if (bwd) {                                                 // nocf_mono_bwd.inc: its LDS layout is a compile-time constant of the kernel
-        if (KBD != 1 || base.LDs != MONO_BWD_LDS_S || base.GLD != MONO_BWD_GLD || base.ZLD > MONO_BWD_ZLD || n_agents > MONO_BWD_NAG) return NOCF_E_SHAPE;
-        l = mono_bwd_lds(KBM).total;
+        if (KBD > 2 || base.LDs != MONO_BWD_LDS_S || base.GLD != MONO_BWD_GLD || base.ZLD > MONO_BWD_ZLD(KBD) || n_agents > MONO_BWD_NAG(KBD)) return NOCF_E_SHAPE;
+        l = mono_bwd_lds(KBM, KBD).total;
     }
     pl.ldsFloats = l;
     if ((size_t)l * 4 > (bwd ? 160 : 96) * 1024) return NOCF_E_LDS;     // (two input k-blocks with 128 hidden units: 70 KB; one workgroup per CU either way)
@@ -2083,7 +2083,7 @@ size_t nocf_activation_record_floats(int32_t d, int32_t m, int32_t nTh, int64_t 
     // shapes with a recording kernel: the split-role kernel's (m = 512) and the one-CU kernel's (m <= 128 in whole 16-blocks, d+1 <= 16;
     // whether that kernel is taken also depends on the problem: `recorded` of the record call says so)
     const bool duo = env_int("NOCF_DUO", 1) != 0 && duo_workspace_bytes(d, m, nTh, d + 1 < 10 ? d + 1 : 10, 1, n, &dummy) == 0;
-    const bool mono = env_int("NOCF_MONO", 1) != 0 && env_int("NOCF_MONO_REC", 1) != 0 && m <= 128 && (m % 16) == 0 && d + 1 <= 16 && m > 32;
+    const bool mono = env_int("NOCF_MONO", 1) != 0 && env_int("NOCF_MONO_REC", 1) != 0 && m <= 128 && (m % 16) == 0 && d + 1 <= 32 && m > 32;
     if (!duo && !mono) return 0;
     return (size_t)nt * ((stepper == NOCF_RK4) ? 4 : 1) * (size_t)n * (size_t)(4 * m + d + 1);
 #endif
@@ -2289,7 +2289,7 @@ int64_t nocf_mid_grad_rows(int32_t d, int32_t m, int32_t nTh, int32_t r, int32_t
     if (make_plan(d, m, nTh, r, n_agents, &pl, 0)) return 0;
     MonoPlan mpl;
     if (make_mono_plan(pl, n_agents, &mpl, true)) return 0;
-    if (!((mpl.KBM == 8 || mpl.KBM == 6 || mpl.KBM == 4) && mpl.KBD == 1)) return 0;
+    if (!((mpl.KBM == 8 || mpl.KBM == 6 || mpl.KBM == 4) && (mpl.KBD == 1 || mpl.KBD == 2))) return 0;
     return std::min<int64_t>((n + 15) / 16, 1024);           // workgroups = partial vectors: beyond 1024 tiles a workgroup takes several
 #endif
 }
@@ -2337,8 +2337,11 @@ int nocf_rollout_bwd_mid_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
     ba.gpart = gpart; ba.gstride = nocf_small_grad_floats(phi->d, phi->m);
     ba.act = (act_rec && (phi->m % 16) == 0) ? act_rec : nullptr; ba.actRows = (long)nt * ba.nstage * n;
     const size_t ldsBytes = (size_t)mpl.pp.ldsFloats * 4;
-    const void* fk = (mpl.KBM == 8) ? reinterpret_cast<const void*>(rollout_mono_bwd_kernel<8, 1>)
-                   : (mpl.KBM == 6) ? reinterpret_cast<const void*>(rollout_mono_bwd_kernel<6, 1>) : reinterpret_cast<const void*>(rollout_mono_bwd_kernel<4, 1>);
+    const void* fk = nullptr;
+#define NOCF_MBW_PICK(M_, D_) if (mpl.KBM == M_ && mpl.KBD == D_) fk = reinterpret_cast<const void*>(rollout_mono_bwd_kernel<M_, D_>);
+    NOCF_MBW_PICK(8, 1) NOCF_MBW_PICK(6, 1) NOCF_MBW_PICK(4, 1) NOCF_MBW_PICK(8, 2) NOCF_MBW_PICK(6, 2) NOCF_MBW_PICK(4, 2)
+#undef NOCF_MBW_PICK
+    if (!fk) return NOCF_E_SHAPE;
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e) return (int)e;
     if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] mono adjoint kernel: %d hidden k-blocks, LDS %zu B/workgroup\n", mpl.KBM, ldsBytes);

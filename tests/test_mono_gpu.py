@@ -155,12 +155,13 @@ def test_mono_adjoint_against_both_per_tile_adjoints(n, nt, stepper, monkeypatch
 @pytest.mark.parametrize("name,n,stepper,training,m_", [
     ("singlequad", 11, "rk4", True, 128), ("singlequad", 21, "rk1", False, 64), ("singlequad", 33, "rk4", True, 120), ("singlequad", 17, "rk4", True, 96),
     ("midcross4", 25, "rk4", True, 80), ("singlequad", 9, "rk4", False, 104),
+    ("swap12", 21, "rk4", True, 64), ("swap12", 9, "rk1", False, 128), ("swap12_5pair", 33, "rk4", True, 96), ("swap12_4pair", 5, "rk4", False, 48),
     ("midcross4", 13, "rk4", True, 128), ("midcross4", 16, "rk1", False, 64), ("softcorridor", 7, "rk4", True, 64),
     ("midcross4", 40, "rk4", False, 128), ("swap2", 1, "rk4", True, 48), ("midcross2", 9, "rk4", False, 128)])
 def test_mono_adjoint_against_oracle_fp64_autograd(name, n, stepper, training, m_):
-    """the one-CU adjoint on medium networks of every problem class with d + 1 <= 16 (quadcopter physics; point agents with obstacle and
-    interaction terms, both mask modes), ragged batches, hidden widths that are padded: dJc/dtheta against the oracle differentiated by
-    torch autograd in fp64"""
+    """the one-CU adjoint on medium networks of every problem class with d + 1 <= 32 (quadcopter physics; point agents with obstacle and
+    interaction terms, both mask modes; one and two input k-blocks), ragged batches, hidden widths that are padded: dJc/dtheta against the
+    oracle differentiated by torch autograd in fp64"""
     from neuraloc_amd import _lib
     from util_hip import synth_state_dict as _synth_state_dict
     from test_hip_parity import _oracle_grads64
