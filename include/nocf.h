@@ -269,7 +269,7 @@ int nocf_rollout_bwd_small_f32(const NocfPhi* phi, const NocfProb* prob, int64_t
                                float* gpart, float* lam0, void* stream);
 
 /*
- * The same adjoint for MEDIUM two-layer networks (nTh = 2, 32 < m <= 128, d+1 <= 16, every problem class: the shapes the one-CU
+ * The same adjoint for MEDIUM two-layer networks (nTh = 2, 32 < m <= 128, d+1 <= 32, every problem class: the shapes the one-CU
  * weight-stationary kernel of nocf_rollout_f32 takes, e.g. singlequad; reference: trainOC.py:172-174 on src/OCflow.py:7-140).  One
  * workgroup per 16 samples keeps the network in its registers, takes grad Phi's activations from the forward's activation record
  * (act_rec of nocf_rollout_record_act_f32, requested one evaluation ahead; null or `recorded` = 0: it re-runs grad Phi at the recorded
