@@ -255,6 +255,18 @@ size_t nocf_dw_scratch_floats(void);
 int nocf_poison_if_failed_f32(float* buf, int64_t count, void* stream);
 
 /*
+ * Parameter gradients of the stand-alone value call Phi(s) (src/Phi.py:91-96 under torch autograd: `net(x).backward(gout)`), any depth:
+ * the rows whose outer products are the gradients, in the layout of nocf_rollout_bwd_f32 with nt = 0 (two blocks of n rows; the SECOND
+ * block carries the value's rows, the first one is zero cotangents):  dK0 = Ob' Sx, db0 = colsum(Ob), dK_i = Qb_i' U0_i, db_i = colsum(Qb_i),
+ * dw = colsum(Wb), dc.weight = gout' s, dc.bias = sum(gout), d(A'A) = 1/2 (s . gout)' s.  dPhi/ds is nocf_phi_grad_f32 times gout.
+ *   s     device [n, d+1];   gout  device [n]: the cotangent of Phi(s), an INPUT
+ *   Y, Ob, Wb  device [2 n, m];  V, Ab, Qb, U0  device [nTh-1, 2 n, m];  Gb, Sx  device [2 n, d+1]  (Y, V, Ab, Gb: second block zeroed by the caller)
+ */
+int nocf_phi_value_bwd_f32(const NocfPhi* phi, const float* s, int64_t n, float* gout,
+                           float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The same adjoint for SMALL networks (nTh = 2, m <= 32, d+1 <= 32, Cross2D agents: the shapes the lane kernel of
  * nocf_rollout_f32 takes), one wavefront per sample with every weight-gradient row in registers: nothing is streamed and
  * nothing is left to contract.  Returns NOCF_E_SHAPE for any other shape (use nocf_rollout_bwd_f32 then).
