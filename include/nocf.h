@@ -267,6 +267,17 @@ int nocf_phi_value_bwd_f32(const NocfPhi* phi, const float* s, int64_t n, float*
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The vector-Jacobian product of the stand-alone gradient call (src/Phi.py:99-138 under torch autograd: `net.getGrad(x).backward(gbar)`), any depth:
+ * sbar = (d grad Phi / d s)' gbar and, in the FIRST block of n rows of the streams (layout of nocf_rollout_bwd_f32 with nt = 0), the rows of the
+ * parameter gradients:  dK0 = Y' Gb + Ob' Sx, db0 = colsum(Ob), dK_i = V_i' Ab_i + Qb_i' U0_i, db_i = colsum(Qb_i), dw = colsum(Wb),
+ * dc.weight = colsum(Gb), d(A'A) = Gb' Sx  (Gb = gbar, Sx = s).
+ *   s, gbar, sbar  device [n, d+1];   streams as in nocf_phi_value_bwd_f32 (2 n rows each; only the first n are written)
+ */
+int nocf_phi_grad_bwd_f32(const NocfPhi* phi, const float* s, int64_t n, const float* gbar, float* sbar,
+                          float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The same adjoint for SMALL networks (nTh = 2, m <= 32, d+1 <= 32, Cross2D agents: the shapes the lane kernel of
  * nocf_rollout_f32 takes), one wavefront per sample with every weight-gradient row in registers: nothing is streamed and
  * nothing is left to contract.  Returns NOCF_E_SHAPE for any other shape (use nocf_rollout_bwd_f32 then).

@@ -182,8 +182,8 @@ class Phi(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
                 f"{what}: autograd through this stand-alone call is not built (no reference driver differentiates it); "
-                "Jc.backward() through OCflow(...) and net(x).backward() in single precision are -- neuraloc_amd/train.py, "
-                "Phi.forward.  Call under torch.no_grad()")
+                "in single precision Jc.backward() through OCflow(...), net(x).backward() and net.getGrad(x).backward() are -- "
+                "neuraloc_amd/train.py, Phi.forward, Phi.getGrad.  Call under torch.no_grad()")
 
     def forward(self, x):
         """Phi(s), n-by-1 (src/Phi.py:91-96)."""
@@ -195,6 +195,8 @@ class Phi(nn.Module):
         return self._value_f32(x)
 
     def _value_f32(self, x):
+        if x.dim() != 2 or x.shape[1] != self.d + 1:
+            raise ValueError(f"x must be n-by-{self.d + 1}")
         st, keep, ws = self._c_struct()
         out = torch.empty(x.shape[0], 1, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -208,7 +210,13 @@ class Phi(nn.Module):
         if isinstance(x, torch.Tensor) and x.dtype == torch.float64:
             return self._phi64(x, value=False)
         x = _lib.require_device_f32(x, "x")
-        self._guard_no_autograd(x, "Phi.getGrad")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _PhiGradFn.apply(x, self, *[p for _, p in self.named_parameters()])       # first-order autograd through grad Phi (src/Phi.py:99-138)
+        return self._grad_f32(x)
+
+    def _grad_f32(self, x):
+        if x.dim() != 2 or x.shape[1] != self.d + 1:
+            raise ValueError(f"x must be n-by-{self.d + 1}")
         st, keep, ws = self._c_struct()
         out = torch.empty(x.shape[0], self.d + 1, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -242,7 +250,7 @@ class _PhiValueFn(torch.autograd.Function):
         n, D1, m, L = x.shape[0], net.d + 1, net.m, net.nTh - 1
         g = gout.detach().reshape(-1).to(torch.float32).contiguous()
         with torch.no_grad():
-            gx = net.getGrad(x) * g[:, None] if ctx.x_req else None
+            gx = net._grad_f32(x) * g[:, None] if ctx.x_req else None
             st, keep, ws = net._c_struct(n)
             rows = 2 * n
             Y, Ob, Wb = (torch.empty(rows, m, device=dev) for _ in range(3))
@@ -265,3 +273,52 @@ class _PhiValueFn(torch.autograd.Function):
             dM = 0.5 * (sT * g[:, None]).t() @ sT
             grads["A"] = net.A.detach() @ (dM + dM.t())
         return (gx, None) + tuple(grads[name] for name, _ in net.named_parameters())
+
+
+class _PhiGradFn(torch.autograd.Function):
+    """net.getGrad(x) under autograd (single precision, first order through the gradient = second order in Phi): the backward is the
+    vector-Jacobian product of grad Phi -- the per-tile adjoint's four products per layer on the packed images, nocf_phi_grad_bwd_f32 --
+    which returns (d grad Phi / d x)' gbar and streams the rows of the parameter gradients, contracted here."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        xd = x.detach()
+        if xd.dim() != 2 or xd.shape[1] != net.d + 1:
+            raise ValueError(f"x must be n-by-{net.d + 1}")
+        ctx.net, ctx.x_req = net, bool(x.requires_grad)
+        ctx.save_for_backward(xd)
+        ctx.versions = [p._version for p in net.parameters()]
+        return net._grad_f32(xd)
+
+    @staticmethod
+    def backward(ctx, gbar):
+        (x,) = ctx.saved_tensors
+        net = ctx.net
+        if [p._version for p in net.parameters()] != ctx.versions:
+            raise RuntimeError("Phi backward: a parameter was modified in place between this forward and its backward")
+        dev = x.device
+        n, D1, m, L = x.shape[0], net.d + 1, net.m, net.nTh - 1
+        g = gbar.detach().to(torch.float32).contiguous()
+        with torch.no_grad():
+            st, keep, ws = net._c_struct(n)
+            rows = 2 * n
+            Y, Ob, Wb = (torch.empty(rows, m, device=dev) for _ in range(3))
+            V, Ab, Qb, U0 = (torch.empty(L, rows, m, device=dev) for _ in range(4))
+            Gb, Sx = torch.empty(rows, D1, device=dev), torch.empty(rows, D1, device=dev)
+            sbar = torch.empty(n, D1, device=dev)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().nocf_phi_grad_bwd_f32(
+                    C.byref(st), _lib.ptr(x), n, _lib.ptr(g), _lib.ptr(sbar), _lib.ptr(Y), _lib.ptr(Ob), _lib.ptr(V), _lib.ptr(Ab), _lib.ptr(Qb),
+                    _lib.ptr(U0), _lib.ptr(Wb), _lib.ptr(Gb), _lib.ptr(Sx), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            _lib.check(rc, "nocf_phi_grad_bwd_f32")
+            Y1, Ob1, Wb1, Gb1, Sx1 = Y[:n], Ob[:n], Wb[:n], Gb[:n], Sx[:n]
+            grads = {"N.layers.0.weight": Ob1.t() @ Sx1 + Y1.t() @ Gb1, "N.layers.0.bias": Ob1.sum(0)}
+            for i in range(1, L + 1):
+                grads[f"N.layers.{i}.weight"] = Qb[i - 1, :n].t() @ U0[i - 1, :n] + V[i - 1, :n].t() @ Ab[i - 1, :n]
+                grads[f"N.layers.{i}.bias"] = Qb[i - 1, :n].sum(0)
+            grads["w.weight"] = Wb1.sum(0).reshape(1, -1)
+            grads["c.weight"] = Gb1.sum(0).reshape(1, -1)
+            grads["c.bias"] = torch.zeros(1, device=dev)
+            dM = Gb1.t() @ Sx1
+            grads["A"] = net.A.detach() @ (dM + dM.t())
+        return (sbar if ctx.x_req else None, None) + tuple(grads[name] for name, _ in net.named_parameters())

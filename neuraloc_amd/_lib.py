@@ -242,6 +242,8 @@ def _bind(L):
     if hasattr(L, "nocf_phi_value_bwd_f32"):
         L.nocf_phi_value_bwd_f32.restype = C.c_int
         L.nocf_phi_value_bwd_f32.argtypes = [C.POINTER(NocfPhi), C.c_void_p, C.c_int64, C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.nocf_phi_grad_bwd_f32.restype = C.c_int
+        L.nocf_phi_grad_bwd_f32.argtypes = [C.POINTER(NocfPhi), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]
     L.nocf_contract_f32.restype = C.c_int
     L.nocf_contract_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_size_t, C.c_void_p]

@@ -2102,7 +2102,7 @@ static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n,
                             const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
                             float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
                             float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream,
-                            int value_only = 0);
+                            int value_only = 0, const float* gbar_in = nullptr, float* sbar_out = nullptr);
 
 // ---- training tape + split-role adjoint (nocf_duo_bwd.inc)
 static void tape_offsets(int32_t d, int32_t m, int64_t n, int32_t nt, int32_t stepper, size_t* oU1, size_t* oSc, size_t* total) {
@@ -2217,6 +2217,14 @@ int nocf_rollout_bwd_act_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
                             act_rec, workspace, workspace_bytes, stream);
 }
 
+int nocf_phi_grad_bwd_f32(const NocfPhi* phi, const float* s, int64_t n, const float* gbar, float* sbar,
+                          float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!gbar || !sbar) return NOCF_E_NULL;
+    return rollout_bwd_impl(phi, nullptr, n, 0, NOCF_RK4, 0.0, nullptr, 0.0, s, nullptr, nullptr, Y, Ob, V, Ab, Qb, U0, Wb, Gb, Sx, nullptr, nullptr,
+                            nullptr, workspace, workspace_bytes, stream, 2, gbar, sbar);
+}
+
 int nocf_phi_value_bwd_f32(const NocfPhi* phi, const float* s, int64_t n, float* gout,
                            float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
                            void* workspace, size_t workspace_bytes, void* stream) {
@@ -2229,12 +2237,12 @@ static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n,
                             const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
                             float* Y, float* Ob, float* V, float* Ab, float* Qb, float* U0, float* Wb, float* Gb, float* Sx,
                             float* PHIb, float* lam0, const float* act_rec, void* workspace, size_t workspace_bytes, void* stream,
-                            int value_only) {
+                            int value_only, const float* gbar_in, float* sbar_out) {
     int rc = check_phi(phi);
     if (rc) return rc;
-    if (value_only) { if (!s_all || nt != 0) return NOCF_E_NULL; }
+    if (value_only) { if (!s_all || nt != 0 || (value_only == 2 && (!gbar_in || !sbar_out))) return NOCF_E_NULL; }
     else if (!alph || !z_final || !hs) return NOCF_E_NULL;
-    if (!s_all || !Y || !Ob || !V || !Ab || !Qb || !U0 || !Wb || !Gb || !Sx || !PHIb || !workspace)
+    if (!s_all || !Y || !Ob || !V || !Ab || !Qb || !U0 || !Wb || !Gb || !Sx || (!PHIb && value_only != 2) || !workspace)
         return NOCF_E_NULL;
     if (n < 1 || (nt < 1 && !value_only)) return NOCF_E_SHAPE;
     if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
@@ -2261,7 +2269,7 @@ static int rollout_bwd_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n,
     ba.sAll = s_all; ba.zT = z_final; ba.hs = hs; ba.n = n; ba.nt = nt; ba.nstage = (stepper == NOCF_RK4) ? 4 : 1;
     ba.t1 = (float)t1;
     if (alph) { ba.a0 = alph[0]; ba.a3 = alph[3]; ba.a4 = alph[4]; ba.a5 = alph[5]; } else { ba.a0 = ba.a3 = ba.a4 = ba.a5 = 0.f; }
-    ba.inv_n = (float)inv_n; ba.value_only = value_only;
+    ba.inv_n = (float)inv_n; ba.value_only = value_only; ba.gbar_in = gbar_in; ba.sbar_out = sbar_out;
     ba.Y = Y; ba.Ob = Ob; ba.V = V; ba.Ab = Ab; ba.Qb = Qb; ba.U0 = U0; ba.Wb = Wb; ba.Gb = Gb; ba.Sx = Sx;
     ba.PHIb = PHIb; ba.lam0 = lam0;
     ba.act = (act_rec && phi->nTh == 2) ? act_rec : nullptr; ba.actRows = (long)nt * ba.nstage * n;

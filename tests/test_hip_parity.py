@@ -232,8 +232,8 @@ def test_error_behaviour():
             na.OCflow(x, g_net, prob, [0.0, 1.0], 0)
         with pytest.raises(ValueError):
             na.OCflow(x, g_net, prob, [0.0, 1.0], 4, stepper="rk2")
-    with pytest.raises(NotImplementedError):
-        g_net.getGrad(x)                                   # autograd through the stand-alone Phi calls: not offered
+    with pytest.raises(ValueError):
+        g_net.getGrad(x)                                   # (x without the time column; under autograd or not)
     x0 = x.clone()
     with torch.no_grad():
         na.OCflow(x, g_net, prob, [0.0, 1.0], 2)
