@@ -383,6 +383,22 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob,
                      double* zFull, double* ctrlFull,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Training in double precision (`trainOC.py --prec double`, trainOC.py:44,76-79,172-174): the recording forward and the adjoint of the
+ * discrete RK scheme, every tensor a double.  Same semantics, row streams and contractions as nocf_rollout_record_f32 /
+ * nocf_rollout_bwd_f32 (rows = (nt * nstage + 2) * n; the caller zeroes the last n rows of Y, V, Ab, Gb and contracts in double);
+ * any depth that fits the LDS, all problem classes, rk4 / rk1.
+ *   s_all  device [nt * nstage, n, d+1];   hs  device [nt] step sizes (tk + h) - tk as the forward formed them
+ */
+int nocf_rollout_record_f64(const NocfPhi64* phi, const NocfProb64* prob, const double* x, int64_t n,
+                            double t0, double t1, int32_t nt, int32_t stepper, const double* alph,
+                            double* z_out, double* persample, double* cost_sums, double* s_all,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int nocf_rollout_bwd_f64(const NocfPhi64* phi, const NocfProb64* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                         const double* alph, double inv_n, const double* s_all, const double* z_final, const double* hs,
+                         double* Y, double* Ob, double* V, double* Ab, double* Qb, double* U0, double* Wb, double* Gb, double* Sx,
+                         double* PHIb, double* lam0, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Phi.forward (src/Phi.py:91-96) and Phi.getGrad (:99-138) in double: s device [n, d+1] -> value device [n] (nullable),
  * grad device [n, d+1] (nullable; at least one of the two) */
 int nocf_phi_f64(const NocfPhi64* phi, const double* s, int64_t n, double* value, double* grad,

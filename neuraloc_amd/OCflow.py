@@ -38,7 +38,6 @@ def _launch64(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
         raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
     if len(alph) < 6:
         raise ValueError("alph needs 6 entries")
-    Phi._guard_no_autograd(x, "OCflow (double precision: evaluation only, the adjoint is fp32)")
     phi_st, keep1, ws = Phi._c_struct64()
     prob_st, keep2 = prob._c_struct64(x.device)
     dev = x.device
@@ -139,16 +138,12 @@ def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0
                     like the reference: src/OCflow.py:66-76)
     :return: (Jc, cs)  or  (zFull, ctrlFull)
     """
-    if (torch.is_grad_enabled() and not intermediates and not noMean and x.dtype != torch.float64
+    if (torch.is_grad_enabled() and not intermediates and not noMean
             and (x.requires_grad or any(p.requires_grad for p in Phi.parameters()))):
         from .train import ocflow_train                 # trainOC.py:172-173: Jc.backward() -> hand-written adjoint
         if int(nt) < 1:
             raise ValueError("nt must be >= 1")
         return ocflow_train(x, Phi, prob, tspan, nt, stepper, alph)
-    if (x.dtype == torch.float64 and torch.is_grad_enabled()
-            and (x.requires_grad or any(p.requires_grad for p in Phi.parameters()))):
-        raise NotImplementedError("OCflow in double precision is evaluation only (the adjoint kernels are fp32): call it under "
-                                  "torch.no_grad(); train in single precision (trainOC.py's default)")
     persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates and not noMean)
     if noMean or intermediates:
         # results that are consumed on the host (plots, files): a timed-out exchange must raise HERE, not at the next call

@@ -300,6 +300,15 @@ def _bind(L):
     L.nocf_rollout_f64.argtypes = [C.POINTER(NocfPhi64), C.POINTER(NocfProb64), C.c_void_p, C.c_int64,
                                    C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    if hasattr(L, "nocf_rollout_bwd_f64"):
+        L.nocf_rollout_record_f64.restype = C.c_int
+        L.nocf_rollout_record_f64.argtypes = [C.POINTER(NocfPhi64), C.POINTER(NocfProb64), C.c_void_p, C.c_int64,
+                                              C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.nocf_rollout_bwd_f64.restype = C.c_int
+        L.nocf_rollout_bwd_f64.argtypes = [C.POINTER(NocfPhi64), C.POINTER(NocfProb64), C.c_int64, C.c_int32, C.c_int32, C.c_double,
+                                           C.POINTER(C.c_double), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_void_p] * 11 + \
+                                          [C.c_void_p, C.c_size_t, C.c_void_p]
     L.nocf_prob_eval_f64.restype = C.c_int
     L.nocf_prob_eval_f64.argtypes = [C.POINTER(NocfProb64), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.nocf_phi_f64.restype = C.c_int

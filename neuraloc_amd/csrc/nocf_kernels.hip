@@ -1519,6 +1519,7 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 
 #include "nocf_mono.inc"
 #include "nocf_f64.inc"
+#include "nocf_f64_bwd.inc"
 #include "nocf_lane.inc"
 #include "nocf_bwd.inc"
 #include "nocf_lane_bwd.inc"
@@ -2465,10 +2466,27 @@ size_t nocf_workspace_bytes_f64(int32_t d, int32_t m, int32_t nTh) {
     return f64_ws_doubles(d, m, nTh) * sizeof(double);
 }
 
+static int rollout_f64_impl(const NocfPhi64* phi, const NocfProb64* prob, const double* x, int64_t n,
+                            double t0, double t1, int32_t nt, int32_t stepper, const double* alph,
+                            double* z_out, double* persample, double* cost_sums, double* zFull, double* ctrlFull, double* s_all,
+                            void* workspace, size_t workspace_bytes, void* stream);
 int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob, const double* x, int64_t n,
                      double t0, double t1, int32_t nt, int32_t stepper, const double* alph,
                      double* z_out, double* persample, double* cost_sums, double* zFull, double* ctrlFull,
                      void* workspace, size_t workspace_bytes, void* stream) {
+    return rollout_f64_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, zFull, ctrlFull, nullptr, workspace, workspace_bytes, stream);
+}
+int nocf_rollout_record_f64(const NocfPhi64* phi, const NocfProb64* prob, const double* x, int64_t n,
+                            double t0, double t1, int32_t nt, int32_t stepper, const double* alph,
+                            double* z_out, double* persample, double* cost_sums, double* s_all,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!s_all || !z_out) return NOCF_E_NULL;
+    return rollout_f64_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, nullptr, nullptr, s_all, workspace, workspace_bytes, stream);
+}
+static int rollout_f64_impl(const NocfPhi64* phi, const NocfProb64* prob, const double* x, int64_t n,
+                            double t0, double t1, int32_t nt, int32_t stepper, const double* alph,
+                            double* z_out, double* persample, double* cost_sums, double* zFull, double* ctrlFull, double* s_all,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     if (!phi || !prob) return NOCF_E_NULL;
     if (!phi->K0 || !phi->b0 || !phi->K || !phi->b || !phi->w || !phi->A || !phi->cw || !phi->cb_dev) return NOCF_E_NULL;
     if (!x || !alph || !workspace || !prob->xtarget) return NOCF_E_NULL;
@@ -2496,7 +2514,7 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob, const double*
     hipLaunchKernelGGL(f64_pack_kernel, dim3(512), dim3(256), 0, st, pl, P, ws);
     F64Args ra;
     ra.x = x; ra.n = n; ra.t0 = t0; ra.t1 = t1; ra.h = (t1 - t0) / nt; ra.nt = nt; ra.stepper = stepper; ra.a0 = alph[0];
-    ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull;
+    ra.z_out = z_out; ra.persample = persample; ra.zFull = zFull; ra.ctrlFull = ctrlFull; ra.sAll = s_all;
     ra.cdim = nocf_ctrl_dim(&p32, phi->d);
 #ifdef NOCF_STAMPS
     { const int dbg = env_int("NOCF_F64_DBG", 0); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f64_dbg), &dbg, sizeof(dbg)); }
@@ -2518,6 +2536,61 @@ int nocf_rollout_f64(const NocfPhi64* phi, const NocfProb64* prob, const double*
     if (cost_sums) hipLaunchKernelGGL(f64_cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums);
     e = hipGetLastError();
     return (int)e;
+}
+
+// the adjoint in double precision (nocf_f64_bwd.inc): rows streamed in the layout of nocf_rollout_bwd_f32
+int nocf_rollout_bwd_f64(const NocfPhi64* phi, const NocfProb64* prob, int64_t n, int32_t nt, int32_t stepper, double t1,
+                         const double* alph, double inv_n, const double* s_all, const double* z_final, const double* hs,
+                         double* Y, double* Ob, double* V, double* Ab, double* Qb, double* U0, double* Wb, double* Gb, double* Sx,
+                         double* PHIb, double* lam0, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!phi || !prob) return NOCF_E_NULL;
+    if (!phi->K0 || !phi->b0 || !phi->K || !phi->b || !phi->w || !phi->A || !phi->cw || !phi->cb_dev) return NOCF_E_NULL;
+    if (!alph || !s_all || !z_final || !hs || !Y || !Ob || !V || !Ab || !Qb || !U0 || !Wb || !Gb || !Sx || !PHIb || !workspace || !prob->xtarget) return NOCF_E_NULL;
+    if (n < 1 || nt < 1 || phi->d < 1 || phi->m < 1 || phi->nTh < 2 || phi->r < 1 || phi->r > 16) return NOCF_E_SHAPE;
+    if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
+    NocfProb p32;
+    p32.kind = prob->kind; p32.obstacle = prob->obstacle; p32.n_agents = prob->n_agents; p32.training = prob->training;
+    p32.r = prob->r; p32.alph_Q = prob->alph_Q; p32.alph_W = prob->alph_W; p32.mass = prob->mass; p32.grav = prob->grav; p32.xtarget = nullptr;
+    DevProb pb32;
+    int rc = fill_prob(&p32, phi->d, &pb32);
+    if (rc) return rc;
+    F64Prob pb{pb32.kind, pb32.obstacle, pb32.nAgents, pb32.training, pb32.agentDim, prob->r, prob->alph_Q, prob->alph_W, prob->mass, prob->grav, prob->xtarget};
+    if (workspace_bytes < nocf_workspace_bytes_f64(phi->d, phi->m, phi->nTh)) return NOCF_E_WORKSPACE;
+    const bool wide = phi->m > 256;                            // (the register-tiled products; they run at 2 or 1 samples per workgroup here)
+    F64BwdPlan bp;
+    int T = 0;
+    for (int cand : {4, 2, 1}) {
+        if (wide && cand == 4) continue;
+        if (make_f64_bwd_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cand, &bp) == 0) { T = cand; break; }
+    }
+    if (!T) return NOCF_E_LDS;
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+    F64Phi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev, phi->d, phi->m, phi->nTh, phi->r};
+    {   // the transposed images K0T / KT of the evaluation kernel's workspace (the packed MFMA images are not used here)
+        F64Plan plf;
+        if (make_f64_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, 1, &plf)) return NOCF_E_LDS;
+        hipLaunchKernelGGL(f64_pack_kernel, dim3(512), dim3(256), 0, st, plf, P, ws);
+    }
+    F64BwdArgs ba;
+    ba.sAll = s_all; ba.zT = z_final; ba.hs = hs; ba.n = n; ba.nt = nt; ba.nstage = (stepper == NOCF_RK4) ? 4 : 1;
+    ba.t1 = t1; ba.a0 = alph[0]; ba.a3 = alph[3]; ba.a4 = alph[4]; ba.a5 = alph[5]; ba.inv_n = inv_n;
+    ba.Y = Y; ba.Ob = Ob; ba.Wb = Wb; ba.V = V; ba.Ab = Ab; ba.Qb = Qb; ba.U0 = U0; ba.lstride = ((long)nt * ba.nstage + 2) * n * phi->m;
+    ba.Gb = Gb; ba.Sx = Sx; ba.PHIb = PHIb; ba.lam0 = lam0;
+    const size_t ldsBytes = (size_t)bp.ldsDoubles * 8;
+    const void* fk = wide ? (T == 2 ? reinterpret_cast<const void*>(rollout_bwd_f64_kernel<2, true>) : reinterpret_cast<const void*>(rollout_bwd_f64_kernel<1, true>))
+                          : (T == 4 ? reinterpret_cast<const void*>(rollout_bwd_f64_kernel<4, false>)
+                             : T == 2 ? reinterpret_cast<const void*>(rollout_bwd_f64_kernel<2, false>) : reinterpret_cast<const void*>(rollout_bwd_f64_kernel<1, false>));
+    hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e) return (int)e;
+    if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] f64 adjoint kernel: %d sample(s) per workgroup, LDS %zu B\n", T, ldsBytes);
+    const double* wsc = ws;
+    void* args[] = {(void*)&bp, (void*)&P, (void*)&pb, (void*)&wsc, (void*)&ba};
+    e = hipLaunchKernel(fk, dim3((unsigned)((n + T - 1) / T)), dim3(256), args, ldsBytes, st);
+    if (e) return (int)e;
+    g_last_kernel = "rollout_bwd_f64_kernel";
+    g_last_errp = nullptr;
+    return (int)hipGetLastError();
 }
 
 int nocf_phi_f64(const NocfPhi64* phi, const double* s, int64_t n, double* value, double* grad,

@@ -363,6 +363,97 @@ class _OCflowTrain(torch.autograd.Function):
         return (gx,) + (None,) * 8 + tuple(out)
 
 
+class _OCflowTrain64(torch.autograd.Function):
+    """the same in double precision (trainOC.py --prec double): nocf_rollout_record_f64 + nocf_rollout_bwd_f64 (csrc/nocf_f64_bwd.inc), the
+    streamed rows contracted with double GEMMs"""
+
+    @staticmethod
+    def forward(ctx, x, net, prob, tspan, nt, stepper, alph, n_total, group, *params):
+        ctx.x_needs_grad = bool(x.requires_grad)
+        x = _lib.require_device_f64(x.detach(), "x")
+        if x.dim() != 2:
+            raise ValueError("x must be nex-by-d")
+        n, d = x.shape
+        if d != net.d:
+            raise ValueError(f"x has d={d} but Phi was built for d={net.d}")
+        if len(alph) < 6:
+            raise ValueError("alph needs 6 entries")
+        dev = x.device
+        phi_st, keep1, ws = net._c_struct64()
+        prob_st, keep2 = prob._c_struct64(dev)
+        nstage = 4 if stepper == "rk4" else 1
+        persample = torch.empty(n, 7, dtype=torch.float64, device=dev)
+        sums = torch.empty(8, dtype=torch.float64, device=dev)
+        z_out = torch.empty(n, d + 4, dtype=torch.float64, device=dev)
+        s_all = torch.empty(nt * nstage, n, d + 1, dtype=torch.float64, device=dev)
+        alph_c = (C.c_double * 6)(*[float(a) for a in alph[:6]])
+        with torch.cuda.device(dev):
+            rc = _lib.lib().nocf_rollout_record_f64(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n, float(tspan[0]), float(tspan[1]), int(nt),
+                                                    _STEPPERS[stepper], alph_c, _lib.ptr(z_out), _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(s_all),
+                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "nocf_rollout_record_f64")
+        ctx.net, ctx.prob, ctx.tspan, ctx.nt, ctx.stepper, ctx.alph, ctx.group = net, prob, tspan, nt, stepper, list(alph), group
+        if group is not None:
+            from .distributed import reduce_cost_sums
+            sums = reduce_cost_sums(sums, None if group is True else group)
+            if not n_total:
+                n_total = int(round(float(sums[7].item())))
+        ctx.n_total = n_total or n
+        ctx.save_for_backward(s_all, z_out)
+        ctx.param_versions = [p._version for p in net.parameters()]
+        means = sums[:7] / sums[7]
+        Jc = means[0] + alph[0] * means[1] + alph[3] * means[2] + alph[4] * means[3] + alph[5] * means[4]
+        return Jc, means.detach()
+
+    @staticmethod
+    def backward(ctx, gJ, _gmeans):
+        s_all, z_out = ctx.saved_tensors
+        net, prob, nt, alph = ctx.net, ctx.prob, ctx.nt, ctx.alph
+        if [p._version for p in net.parameters()] != ctx.param_versions:
+            raise RuntimeError("OCflow backward: a parameter of Phi was modified in place between this forward and its backward")
+        dev = s_all.device
+        n, d = z_out.shape[0], z_out.shape[1] - 4
+        m, D1, L = net.m, d + 1, net.nTh - 1
+        nstage = 4 if ctx.stepper == "rk4" else 1
+        rows = (nt * nstage + 2) * n
+        phi_st, keep1, ws = net._c_struct64()
+        prob_st, keep2 = prob._c_struct64(dev)
+        h = (float(ctx.tspan[1]) - float(ctx.tspan[0])) / nt
+        tk, hs_l = float(ctx.tspan[0]), []
+        for _ in range(nt):
+            hs_l.append((tk + h) - tk)
+            tk += h
+        hs = torch.tensor(hs_l, dtype=torch.float64, device=dev)
+        alph_c = (C.c_double * 6)(*[float(a) for a in alph[:6]])
+        f64 = dict(dtype=torch.float64, device=dev)
+        lam0 = torch.empty(n, d, **f64) if ctx.x_needs_grad else None
+        Y, Ob, Wb = (torch.empty(rows, m, **f64) for _ in range(3))
+        V, Ab, Qb, U0 = (torch.empty(L, rows, m, **f64) for _ in range(4))
+        Gb, Sx = torch.empty(rows, D1, **f64), torch.empty(rows, D1, **f64)
+        for t in (Y, Gb):
+            t[rows - n:].zero_()
+        for t in (V, Ab):
+            t[:, rows - n:].zero_()
+        PHIb = torch.zeros(n, **f64)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().nocf_rollout_bwd_f64(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper], float(ctx.tspan[1]), alph_c,
+                                                 1.0 / float(ctx.n_total), _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs),
+                                                 _lib.ptr(Y), _lib.ptr(Ob), _lib.ptr(V), _lib.ptr(Ab), _lib.ptr(Qb), _lib.ptr(U0), _lib.ptr(Wb),
+                                                 _lib.ptr(Gb), _lib.ptr(Sx), _lib.ptr(PHIb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "nocf_rollout_bwd_f64")
+        sT = Sx[(nt * nstage + 1) * n:]
+        grads = {"N.layers.0.weight": Ob.t() @ Sx + Y.t() @ Gb, "N.layers.0.bias": Ob.sum(0)}
+        for i in range(1, L + 1):
+            grads[f"N.layers.{i}.weight"] = Qb[i - 1].t() @ U0[i - 1] + V[i - 1].t() @ Ab[i - 1]
+            grads[f"N.layers.{i}.bias"] = Qb[i - 1].sum(0)
+        grads["w.weight"] = Wb.sum(0).reshape(1, -1)
+        grads["c.weight"] = (Gb.sum(0) + PHIb @ sT).reshape(1, -1)
+        grads["c.bias"] = PHIb.sum().reshape(1)
+        dM = Gb.t() @ Sx + 0.5 * (sT * PHIb[:, None]).t() @ sT
+        grads["A"] = net.A.detach() @ (dM + dM.t())
+        return _OCflowTrain._finish(ctx, gJ, grads, lam0, net)
+
+
 def ocflow_train(x, net, prob, tspan, nt, stepper, alph, n_total=None, group=None):
     """(Jc, cs) with Jc differentiable w.r.t. the parameters of `net`.  n_total: global batch size when x is one
     shard of it (the means of src/OCflow.py:80-86 run over all samples).  group: a torch.distributed process group
@@ -372,5 +463,6 @@ def ocflow_train(x, net, prob, tspan, nt, stepper, alph, n_total=None, group=Non
     if stepper not in _STEPPERS:
         raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
     params = [p for _, p in net.named_parameters()]
-    Jc, means = _OCflowTrain.apply(x, net, prob, list(tspan), int(nt), stepper, list(alph), n_total, group, *params)
+    fn = _OCflowTrain64 if x.dtype == torch.float64 else _OCflowTrain
+    Jc, means = fn.apply(x, net, prob, list(tspan), int(nt), stepper, list(alph), n_total, group, *params)
     return Jc, [means[i] for i in range(7)]
