@@ -125,8 +125,8 @@ def costs_from_sums(sums, alph):
 def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0],
            intermediates=False, noMean=False):
     """
-    :param x:       nex-by-d tensor on the MI355X, fp32 (or float64 together with Phi and prob: the reference's --prec double,
-                    evaluation only)
+    :param x:       nex-by-d tensor on the MI355X, fp32 (or float64 together with Phi and prob: the reference's --prec double;
+                    differentiable in both precisions)
     :param Phi:     neuraloc_amd.Phi
     :param prob:    neuraloc_amd problem object (Cross2D / SwarmTraj / Quadcopter)
     :param tspan:   [t0, t1]

@@ -33,6 +33,18 @@ def test_short_training_run_and_checkpoint_roundtrip(tmp_path, capsys):
     assert torch.isfinite(Jc) and best < float("inf")
 
 
+def test_short_training_run_in_double_precision(tmp_path, capsys):
+    """trainOC.py --prec double (trainOC.py:44,76-79): rollout, adjoint and Adam in float64"""
+    import trainOC
+    trainOC.main(["--data", "softcorridor", "--niters", "30", "--val_freq", "10", "--n_train", "128", "--nt", "8",
+                  "--m", "16", "--save", str(tmp_path), "--seed", "1", "--lr", "0.02", "--sample_freq", "100", "--prec", "double"])
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln[:5].isdigit()]
+    assert len(lines) == 30
+    first, last = float(lines[0].split()[3]), float(lines[-1].split()[3])
+    assert last < 0.7 * first, (first, last)
+
+
 def test_evalOC_on_a_reference_checkpoint(tmp_path, capsys):
     """evalOC.py with the reference's flag set on a checkpoint in the reference's layout (weights = the pretrained softcorridor
     network of tests/golden/softcorridor.npz): the printed costs on xInit are the reference's known answers (SURVEY 8(c),

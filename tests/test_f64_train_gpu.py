@@ -44,7 +44,15 @@ def test_double_precision_backward_against_oracle_autograd(name, n, stepper, tra
         scale = w.abs().max().item()
         err = (p.grad.cpu() - w.reshape(p.shape)).abs().max().item()
         assert p.grad.dtype == F64 and err <= 1e-9 * scale + 1e-12, f"{name} {k}: err {err:g} at scale {scale:g}"
-    assert xx.grad is not None and torch.isfinite(xx.grad).all()
+    # dJc/dx0 against the oracle differentiated with respect to the initial states
+    from oracle import ocflow_oracle as orc
+    P = orc.PhiParams.from_state_dict({k: v.clone() for k, v in sd.items()}, dtype=F64)
+    S = orc.ProbSpec.from_object(prob)
+    S.xtarget = S.xtarget.cpu()
+    xo = x0.detach().cpu().clone().requires_grad_(True)
+    Jo, _ = orc.rollout(xo, P, S.to(F64), [0.0, 1.0], nt, stepper, alph)
+    Jo.backward()
+    assert float((xx.grad.cpu() - xo.grad).abs().max()) <= 1e-9 * float(xo.grad.abs().max()) + 1e-12
 
 
 def test_double_precision_training_step_reduces_the_objective():

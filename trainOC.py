@@ -38,7 +38,7 @@ _FLAGS = [
     ("resume", str, None, "checkpoint to continue from"),
     ("save", str, "experiments/oc/run", "output directory"),
     ("gpu", int, 0, "device index of a single-process run"),
-    ("prec", str, "single", "the HIP path is fp32"),
+    ("prec", str, "single", "single or double (trainOC.py:44,76-79): double runs the whole training -- rollout, adjoint, Adam -- in float64"),
     ("approach", str, "ocflow", ""),
     ("lr_reload", str, "alias", "(addition) alias: the reference's behaviour (its reload at lr_freq is a no-op); clone: really roll back to the best validated parameters and reset Adam's moments"),
     ("viz_freq", int, 100, "ignored: nothing is plotted"),
@@ -52,7 +52,7 @@ _FLAGS = [
     ("new_alph", str, None, "'iter, a0, ..., a5': switch the weights at that iteration"),
     ("seed", int, None, "torch seed (rank is added); the reference is unseeded"),
 ]
-_CHOICES = {"data": PROBLEM_NAMES, "optim": ["adam"], "prec": ["single"], "approach": ["ocflow"]}
+_CHOICES = {"data": PROBLEM_NAMES, "optim": ["adam"], "prec": ["single", "double"], "approach": ["ocflow"]}
 
 
 def parse_args(argv=None):
@@ -86,7 +86,8 @@ def main(argv=None):
         torch.manual_seed(args.seed + rank)
     say = print if rank == 0 else (lambda *a, **k: None)
     n_change = int(args.new_alph[0]) if args.new_alph is not None else -1
-    cvt = lambda t: t.to(torch.float32).to(dev)                        # noqa: E731
+    prec = torch.float64 if args.prec == "double" else torch.float32
+    cvt = lambda t: t.to(prec).to(dev)                                 # noqa: E731
     lo, hi = na.shard_rows(args.n_train, rank, world)
     n_local = hi - lo
     alph = args.alph
@@ -99,7 +100,7 @@ def main(argv=None):
         m, nTh = ck["args"].m, ck["args"].nTh
         net = na.Phi(nTh=nTh, m=m, d=d, alph=alph)                      # alph from the command line wins (trainOC.py:129)
         net.load_state_dict(ck["state_dict"])
-    net = net.to(torch.float32).to(dev)
+    net = net.to(prec).to(dev)
     if dist:                                                           # identical initial parameters on every rank
         for prm in net.parameters():
             dist.broadcast(prm.data, src=0)
