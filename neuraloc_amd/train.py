@@ -43,7 +43,7 @@ def _contract(X, Y, out=None):
     if S > 1 and X.is_contiguous() and Y.is_contiguous():
         r = torch.bmm(X.view(S, K // S, m).transpose(1, 2), Y.view(S, K // S, n)).sum(0)
         return r if out is None else out.add_(r)
-    if m > 512 or n > 512 or m * n > 128 * 160:
+    if m > 512 or n > 512 or m * n > 128 * 160 or X.dtype != torch.float32:
         r = X.t() @ Y
         return r if out is None else out.add_(r)
     dev = X.device
@@ -442,14 +442,15 @@ class _OCflowTrain64(torch.autograd.Function):
                                                  _lib.ptr(Gb), _lib.ptr(Sx), _lib.ptr(PHIb), _lib.ptr(lam0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "nocf_rollout_bwd_f64")
         sT = Sx[(nt * nstage + 1) * n:]
-        grads = {"N.layers.0.weight": Ob.t() @ Sx + Y.t() @ Gb, "N.layers.0.bias": Ob.sum(0)}
+        # (the row-slab form of _contract: one GEMM with a small output and ~10^6 rows runs on a handful of workgroups)
+        grads = {"N.layers.0.weight": _contract(Ob, Sx, _contract(Y, Gb)), "N.layers.0.bias": Ob.sum(0)}
         for i in range(1, L + 1):
-            grads[f"N.layers.{i}.weight"] = Qb[i - 1].t() @ U0[i - 1] + V[i - 1].t() @ Ab[i - 1]
+            grads[f"N.layers.{i}.weight"] = _contract(Qb[i - 1], U0[i - 1], _contract(V[i - 1], Ab[i - 1]))
             grads[f"N.layers.{i}.bias"] = Qb[i - 1].sum(0)
         grads["w.weight"] = Wb.sum(0).reshape(1, -1)
         grads["c.weight"] = (Gb.sum(0) + PHIb @ sT).reshape(1, -1)
         grads["c.bias"] = PHIb.sum().reshape(1)
-        dM = Gb.t() @ Sx + 0.5 * (sT * PHIb[:, None]).t() @ sT
+        dM = _contract(Gb, Sx) + 0.5 * (sT * PHIb[:, None]).t() @ sT
         grads["A"] = net.A.detach() @ (dM + dM.t())
         return _OCflowTrain._finish(ctx, gJ, grads, lam0, net)
 
