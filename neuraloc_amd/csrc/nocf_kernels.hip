@@ -2559,8 +2559,10 @@ int nocf_rollout_bwd_f64(const NocfPhi64* phi, const NocfProb64* prob, int64_t n
     const bool wide = phi->m > 256;                            // (the register-tiled products; they run at 2 or 1 samples per workgroup here)
     F64BwdPlan bp;
     int T = 0;
+    const int tpref = env_int("NOCF_F64_BWD_T", 0);             // (diagnostic: force the samples per workgroup)
     for (int cand : {4, 2, 1}) {
         if (wide && cand == 4) continue;
+        if (tpref && cand > tpref) continue;
         if (make_f64_bwd_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cand, &bp) == 0) { T = cand; break; }
     }
     if (!T) return NOCF_E_LDS;
