@@ -255,7 +255,7 @@ def quick_measure(name, dev, steps=10, warmup=3):
             "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of": "fp32 MFMA / vector peak 157.3 TFLOP/s (the small networks are latency-bound VALU work: SURVEY 8d)"}
 
 
-def train_measure(name, dev, reps=5):
+def train_measure(name, dev, reps=10):
     """One training iteration of trainOC.py:170-174 (zero_grad, Jc = OCflow(...), Jc.backward(), Adam step) at the workload's full size,
     prob.train(): wall time per iteration, the two rollout kernels' own times (HIP events recorded by the library around the recording
     forward and around the adjoint) and the fraction of the fp32 MFMA roof: an iteration is 3 x the forward's algorithmic FLOPs (forward,
@@ -275,15 +275,25 @@ def train_measure(name, dev, reps=5):
         L.nocf_profile_end(C.byref(kms), C.byref(nl))
         return r, kms.value, L.nocf_last_rollout_kernel().decode()
 
-    for _ in range(2):
+    for _ in range(3):
         opt.zero_grad()
         Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph)
         Jc.backward()
         opt.step()
     torch.cuda.synchronize()
-    fwd_ms = bwd_ms = 0.0
+    # wall time: the loop as a training run executes it (the host runs ahead of the GPU; one synchronisation at the end)
     t0 = time.perf_counter()
     for _ in range(reps):
+        opt.zero_grad()
+        Jc, _ = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph)
+        Jc.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    # the two rollout kernels' own times: separate iterations (reading a profile window synchronises, which would sit inside the wall time)
+    fwd_ms = bwd_ms = 0.0
+    kreps = 3
+    for _ in range(kreps):
         opt.zero_grad()
         (Jc, _), ms, fk = window(lambda: na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph))
         fwd_ms += ms
@@ -291,12 +301,11 @@ def train_measure(name, dev, reps=5):
         bwd_ms += ms
         opt.step()
     torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / reps
     na.check_errors(sync=True)
     fl = 3.0 * flops_per_state_step(meta) * n * nt
     return {"workload": f"train {name} d={meta['d']} m={meta['m']} nt={nt} n={n} (Adam step, prob.train())", "train_iter_ms": 1e3 * el,
-            "trained_traj_per_s": n / el, "forward_kernel": fk, "forward_kernel_ms": fwd_ms / reps,
-            "adjoint_kernel": bk, "adjoint_kernel_ms": bwd_ms / reps, "flops_per_iteration": fl,
+            "trained_traj_per_s": n / el, "forward_kernel": fk, "forward_kernel_ms": fwd_ms / kreps,
+            "adjoint_kernel": bk, "adjoint_kernel_ms": bwd_ms / kreps, "flops_per_iteration": fl,
             "frac": fl / el / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "frac_of": "3 x SURVEY 8(d) forward FLOPs per iteration over the WHOLE iteration's wall time, of the fp32 MFMA peak", "Jc": float(Jc)}
 
