@@ -2581,8 +2581,8 @@ int nocf_rollout_bwd_f64(const NocfPhi64* phi, const NocfProb64* prob, int64_t n
     ba.Gb = Gb; ba.Sx = Sx; ba.PHIb = PHIb; ba.lam0 = lam0;
     const size_t ldsBytes = (size_t)bp.ldsDoubles * 8;
     const void* fk = wide ? (T == 2 ? reinterpret_cast<const void*>(rollout_bwd_f64_kernel<2, true>) : reinterpret_cast<const void*>(rollout_bwd_f64_kernel<1, true>))
-                          : (T == 4 ? reinterpret_cast<const void*>(rollout_bwd_f64_kernel<4, false>)
-                             : T == 2 ? reinterpret_cast<const void*>(rollout_bwd_f64_kernel<2, false>) : reinterpret_cast<const void*>(rollout_bwd_f64_kernel<1, false>));
+                          : (T == 4 ? reinterpret_cast<const void*>(rollout_bwd_f64_narrow_kernel<4>)
+                             : T == 2 ? reinterpret_cast<const void*>(rollout_bwd_f64_narrow_kernel<2>) : reinterpret_cast<const void*>(rollout_bwd_f64_narrow_kernel<1>));
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e) return (int)e;
     if (env_int("NOCF_DEBUG", 0)) fprintf(stderr, "[nocf] f64 adjoint kernel: %d sample(s) per workgroup, LDS %zu B\n", T, ldsBytes);
