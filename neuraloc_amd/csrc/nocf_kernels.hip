@@ -1598,10 +1598,9 @@ static int make_mono_plan(const DevPlan& base, int n_agents, MonoPlan* out, bool
     pl.lTRIG = take(T * std::max(1, n_agents) * 6);
     pl.lPT = take(4);
     pl.lPW = take(4);
-    if (bwd) {                                                 // nocf_mono_bwd.inc: its LDS layout is a compile-time constant of the kernel
-        if (KBD > 2 || base.LDs != MONO_BWD_LDS_S || base.GLD != MONO_BWD_GLD || base.ZLD > MONO_BWD_ZLD(KBD) || n_agents > MONO_BWD_NAG(KBD)) return NOCF_E_SHAPE;
-        l = mono_bwd_lds(KBM, KBD).total;
-    }
+    // the kernels' LDS layouts are compile-time constants (nocf_mono.inc, nocf_mono_bwd.inc): the shape has to fit their strides and agent counts
+    if (KBD > 2 || base.LDs != MONO_LDS_S || base.GLD != MONO_GLD || base.ZLD > MONO_ZLD(KBD) || n_agents > MONO_NAG(KBD)) return NOCF_E_SHAPE;
+    l = bwd ? mono_bwd_lds(KBM, KBD).total : mono_fwd_lds(KBM, KBD).total;
     pl.ldsFloats = l;
     if ((size_t)l * 4 > (bwd ? 160 : 96) * 1024) return NOCF_E_LDS;     // (two input k-blocks with 128 hidden units: 70 KB; one workgroup per CU either way)
     long o = base.oPlan + (long)rup((int)(sizeof(MonoPlan) / 4), 64);         // floats
