@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NOCF_VERSION 100            /* major*100 + minor */
+#define NOCF_VERSION 110            /* major*100 + minor */
 
 #define NOCF_E_NULL      (-1)       /* required pointer is NULL                     */
 #define NOCF_E_SHAPE     (-2)       /* d/m/nTh/n/nt out of the supported range      */
@@ -235,17 +235,17 @@ int nocf_rollout_bwd_act_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n
  *   lam0 device [n, d] = dJc/dx0 (nullable).  Returns NOCF_E_SHAPE when the shape / problem / residency does not qualify (nothing launched).
  *   A timed-out exchange is reported like the forward's (nocf_last_rollout_status_async); nocf_poison_if_failed_f32 turns a buffer
  *   into NaN on the stream if the last launch on this device failed (call it on the gradients before they are used).
-size_t nocf_tape_floats(int32_t d, int32_t m, int32_t nTh, int64_t n, int32_t nt, int32_t stepper);
-int nocf_rollout_tape_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
-                          double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
-                          float* z_out, float* persample, float* cost_sums, float* s_all, float* tape, int32_t* recorded,
-                          void* workspace, size_t workspace_bytes, void* stream);
  *   Weight-gradient roles (optional): with dK1 device [m, m], dK0 device [m, d+1] and dw_scratch device [nocf_dw_scratch_floats()]
  *   the two large weight gradients are accumulated IN THE KERNEL by two more role workgroups per member that consume the row streams
  *   behind progress counters (csrc/nocf_duo_bwd.inc): on return (*dw_done = 1) dK1 and dK0 hold the complete sums INCLUDING the value's
  *   rows (the caller must then not add phib.v / phib.y to Qb / Ob before using them for anything else; Wb's value rows and the column sums
  *   stay the caller's).  *dw_done = 0: the kernel without those roles ran (NOCF_DUO_DW=0, or NULL pointers) and dK1 / dK0 are untouched.
  */
+size_t nocf_tape_floats(int32_t d, int32_t m, int32_t nTh, int64_t n, int32_t nt, int32_t stepper);
+int nocf_rollout_tape_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                          double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                          float* z_out, float* persample, float* cost_sums, float* s_all, float* tape, int32_t* recorded,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
                               const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
                               const float* tape, float* Y, float* Ab, float* Wb, float* Qb, float* Ob, float* Gb, float* lam0,

@@ -337,6 +337,43 @@ def test_backward_matches_reference_parameter_gradients(name):
         assert err <= 4 * gap + 2e-5 * scale + 1e-7, f"{name} {k}: err {err:g}, reference gap {gap:g}, scale {scale:g}"
 
 
+@pytest.mark.parametrize("name,bwd_kernel", [("swarm50", "rollout_duo_bwd_kernel"), ("singlequad", "rollout_mono_bwd_kernel")])
+def test_backward_at_training_size_matches_reference_parameter_gradients(name, bwd_kernel):
+    """trainOC.py:172-174 at its own size: n_train rows (swarm50 1024 x nt 80, singlequad 4096 x nt 50), prob.train().  Every parameter
+    gradient and Jc against tests/golden/grads_full.npz (make_golden_grads_full.py: the reference's fp32 autograd and the fp64 truth,
+    chunk-summed): the HIP error against fp64 may not exceed 4x the reference's own fp32-vs-fp64 gap + 2e-5 of the gradient scale --
+    the bound of the 16-row test above, now on the batch the bench times (two tiles per group on the split-role adjoint)."""
+    import os
+    from conftest import GOLDEN_DIR, load_golden
+    from neuraloc_amd import _lib
+    G = np.load(os.path.join(GOLDEN_DIR, "grads_full.npz"))
+    g = load_golden(name)
+    nt, n = int(G[f"{name}/nt"]), int(G[f"{name}/n"])
+    assert (n, nt) == (g.meta["n_full"], g.meta["nt"])
+    net = make_net(g, DEV)
+    net.train()
+    prob = make_prob(g, DEV, training=True)
+    x = full_states(g, int(G[f"{name}/seed"])).to(DEV)
+    assert x.shape[0] == n
+    Jc, cs = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", g.meta["alph"])
+    J64, J32 = float(G[f"{name}/Jc64"]), float(G[f"{name}/Jc"])
+    assert abs(Jc.item() - J64) <= 4 * abs(J32 - J64) + 1e-5 * abs(J64), (Jc.item(), J32, J64)
+    for j in range(7):
+        c64, c32 = float(G[f"{name}/cs64"][j]), float(G[f"{name}/cs"][j])
+        assert abs(float(cs[j]) - c64) <= 4 * abs(c32 - c64) + 1e-4 * abs(c64) + 1e-6, (j, float(cs[j]), c32, c64)
+    Jc.backward()
+    assert _lib.lib().nocf_last_rollout_kernel().decode() == bwd_kernel      # the adjoint the bench's training line times
+    for k, p in net.named_parameters():
+        ref32 = torch.from_numpy(G[f"{name}/grad/{k}"]).double()
+        ref64 = torch.from_numpy(G[f"{name}/grad64/{k}"])
+        got = p.grad.detach().cpu().double()
+        assert got.shape == ref64.shape, k
+        scale = ref64.abs().max().item()
+        gap = (ref32 - ref64).abs().max().item()
+        err = (got - ref64).abs().max().item()
+        assert err <= 4 * gap + 2e-5 * scale + 1e-7, f"{name} {k}: err {err:g}, reference gap {gap:g}, scale {scale:g}"
+
+
 def _oracle_grads64(x, sd, prob, nt, stepper, alph, nTh):
     P = orc.PhiParams.from_state_dict({k: v.clone() for k, v in sd.items()}, dtype=torch.float64)
     for t in [*P.K, *P.b, P.w, P.A, P.cw, P.cb]:
