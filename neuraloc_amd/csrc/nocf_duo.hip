@@ -53,7 +53,8 @@
 #include <algorithm>
 #include "nocf_duo.h"
 
-#define DU_G 8
+#define DU_G 8                     // members of a group: the default form (and the adjoint's): 64 hidden units per member
+#define DU_GMAX 16                 // ... and the fine form of the forward (round 5): 16 members of 32 hidden units, see DuoCfg
 #define DU_KBM 32                  // 16-wide k-blocks of the hidden width (m = 512)
 #define DU_KBD 10                  // 16-wide k-blocks of d+1 (<= 160)
 #define DU_DP 160                  // padded d+1
@@ -89,8 +90,27 @@ enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P =
 #define DB_XP (DB_YF + 1024)                       // [4 waves][2]
 #define DB_END (DB_XP + 16)
 
+// The group geometry (round 5).  G members share the 512 hidden units: HPM = 512 / G per member = MTM feature tiles of 16.  A workgroup has
+// four waves: with G = 8 every wave owns one feature tile and the whole contraction range (the form of rounds 3-4); with G = 16 a member
+// has two feature tiles and the waves (mt, kh) = (wave & 1, wave >> 1) split the CONTRACTION of P1 / P2 / P3 in two halves whose partial
+// sums meet in LDS (fixed order: lower half + upper half) -- half the resident slice (64 AccVGPRs), half the MFMAs per product and wave,
+// twice the workgroups per tile.  Where a batch has fewer tiles than the chip has CU pairs (n <= 256 rows: the 4- and 8-GPU shards of
+// n_train = 1024) this is what uses the idle half of the chip; with several tiles per group it shortens every link of the dependency
+// chain that the two roles' tiles interleave on.  An own sample belongs to one member: SPM = 16 / G per member and tile.
+template <int G_> struct DuoCfg {
+    static constexpr int G = G_;
+    static constexpr int HPM = 64 * DU_G / G_;      // hidden units per member
+    static constexpr int MTM = HPM / 16;            // feature tiles per member
+    static constexpr int KS = 4 / MTM;              // waves that share a feature tile (each takes 1 / KS of the contraction)
+    static constexpr int SPM = 16 / G_;             // own samples per member and tile
+    static constexpr int KBW = DU_KBM / KS;         // k-blocks of the hidden width per wave (P2, P3)
+    static constexpr int KB1 = DU_KBD / KS;         // k-blocks of d + 1 per wave (P1)
+    static constexpr int WPG = 2 * G_;              // workgroups per group
+    static_assert(G_ == 8 || G_ == 16, "members per group");
+};
+
 struct DuoPlan {
-    int d, D1, r, nAg, NT, ngroups, spin_max, fast;
+    int d, D1, r, nAg, NT, ngroups, spin_max, fast, G;
     float hN, cb;
     int mapmode, ldsFloats;
     int dbg, dw;                   // dw: the adjoint with the two weight-gradient roles (32 workgroups per group)
@@ -120,7 +140,9 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
         for (long i = gid_; i < nx4; i += stride_) x4[i] = sen;
     }
     const int m = 64 * DU_G, D1 = dp.D1;
-    const long nW = (long)DU_G * 4 * DU_KBM * 64, nK1 = (long)DU_G * 4 * DU_KBD * 64, nK4 = (long)DU_G * DU_KBD * 4 * 64;
+    // (the geometry of DuoCfg at run time: one pack kernel for both forms; every image has the same size in both)
+    const int G = dp.G, HPM = m / G, MTM = HPM / 16, KS = 4 / MTM, KBW = DU_KBM / KS, KB1 = DU_KBD / KS;
+    const long nW = (long)G * 4 * KBW * 64, nK1 = (long)G * 4 * KB1 * 64, nK4 = (long)G * DU_KBD * MTM * 64;
     const long total = 2 * nW + nK1 + nK4;
     const long stride = (long)gridDim.x * blockDim.x;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,31 +153,33 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
             const bool third = idx >= nW;
             long q = third ? idx - nW : idx;
             const int lane = q & 63; q >>= 6;
-            const int kb = q % DU_KBM; q /= DU_KBM;          // q = c*4 + w
-            const int o = (int)q * 16 + (lane & 15);
+            const int kb = q % KBW; q /= KBW;                // q = c*4 + w
+            const int c = (int)q >> 2, w = (int)q & 3;
+            const int o = HPM * c + 16 * (w % MTM) + (lane & 15);
             for (int e = 0; e < 4; ++e) {
-                const int k = 16 * kb + 4 * (lane >> 4) + e;
+                const int k = 16 * ((w / MTM) * KBW + kb) + 4 * (lane >> 4) + e;
                 v[e] = third ? P.K[(long)k * m + o] : P.K[(long)o * m + k];
             }
             dst = (third ? dp.oW3 : dp.oW2) + (third ? idx - nW : idx);
         } else if (idx < 2 * nW + nK1) {
             long q = idx - 2 * nW;
             const int lane = q & 63; q >>= 6;
-            const int kb = q % DU_KBD; q /= DU_KBD;
-            const int o = (int)q * 16 + (lane & 15);
+            const int kb = q % KB1; q /= KB1;
+            const int c = (int)q >> 2, w = (int)q & 3;
+            const int o = HPM * c + 16 * (w % MTM) + (lane & 15);
             for (int e = 0; e < 4; ++e) {
-                const int k = 16 * kb + 4 * (lane >> 4) + e;
+                const int k = 16 * ((w / MTM) * KB1 + kb) + 4 * (lane >> 4) + e;
                 v[e] = (k < D1) ? P.K0[(long)o * D1 + k] : 0.f;
             }
             dst = dp.oK1 + (idx - 2 * nW);
         } else {
             long q = idx - 2 * nW - nK1;
             const int lane = q & 63; q >>= 6;
-            const int kb = q & 3; q >>= 2;
+            const int kb = q % MTM; q /= MTM;
             const int mt = q % DU_KBD; const int cmem = q / DU_KBD;
             const int dim = 16 * mt + (lane & 15);
             for (int e = 0; e < 4; ++e) {
-                const int i = 64 * cmem + 16 * kb + 4 * (lane >> 4) + e;
+                const int i = HPM * cmem + 16 * kb + 4 * (lane >> 4) + e;
                 v[e] = (dim < D1) ? P.K0[(long)i * D1 + dim] : 0.f;
             }
             dst = dp.oK4 + (idx - 2 * nW - nK1);
@@ -200,6 +224,7 @@ __device__ __forceinline__ void mfma_v(f32x4& acc, float w, float b) {
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
 }
 #define DU_FENCE2(a, b) asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b))
+#define DU_FENCE4(a, b, c, d) asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 // Store-data hazard (found in round 4, tools/store_hazard_check.py): a 128-bit buffer store reads its data registers over several cycles;
 // hipcc's hazard recognizer assumes that a store with an SGPR soffset needs no wait state before a VALU instruction overwrites them, and
 // schedules such a write into the very next slot -- on gfx950 the last lanes of every 16 then store the NEW value (the adjoint's obar
@@ -213,7 +238,68 @@ struct DCtx {
     int fast, spin_max;
     bool slow;                     // several tiles per group: longer naps between failed polls (see du_spin)
     bool dead;                     // this wave has seen the error word set (or timed out itself): it no longer waits
+    // Predictive waiting (round 5).  A wave that polls is not free: its requests fill the CU's vector-memory queue and its sentinel tests are
+    // VALU instructions that a co-resident wave's MFMA stream has to make room for (measured with the two roles of a member on one CU:
+    // role B's P4 takes 5.6 k cycles instead of 2.3 k while the role-A waves of its CU poll for S and G -- its three stores queue behind their
+    // requests) -- and the long waits are PERIODIC: role B waits for v through all of role A's step, P1 and P2, an owner for the partial gradients
+    // through P3 and P4, every evaluation alike.  So a wave measures how long a payload took to become valid COUNTED FROM ITS OWN LAST OUTPUT
+    // for that tile (role A: the end of P2, role B: the end of P4 -- the `anchor`), keeps the last two such intervals per exchange kind and tile
+    // in a wave-private LDS slot, and sleeps until anchor + 3/4 of the shorter one - `lead` (~1 000 clocks) before its first poll.  Sleeping costs
+    // no issue slot and no request; the poll loop behind it is unchanged, so a wrong prediction is only ever a nap that ends early or a little
+    // late, never a missed payload.  What this does NOT use, with reasons measured this round: the time since the wave ENTERED the wait (the entry
+    // jitters by thousands of clocks with the co-resident role's work: the owner waves overslept, n = 512 went from 3.36 to 3.56 ms), and the
+    // absolute period of the payload's arrival (a late riser delays everybody behind it on the dependency cycle, which lengthens the very period
+    // the next prediction is made from; four waits per cycle feed that loop and it ran away: evaluations of 300 k cycles).  The interval from the
+    // wave's own output to the payload contains no waiting of this wave, so an overslept nap inflates one measurement and the next one is
+    // true again (and the minimum of the last two is what is used).
+    int udelay;                    // naps (64 clocks each) in front of the FIRST poll for U: see the U gather
+    int pw;                        // LDS float index of this wave's words: [3 kinds][4 tiles][2] intervals, then [4 tiles] anchors; -1: no prediction
+    unsigned qs, lead;             // sleep quanta (64 clocks) per clock tick, 16.16 fixed point; the lead in ticks
 };
+enum { DPW_S = 0, DPW_G = 1, DPW_V = 2, DPW_ANCHOR = 24, DPW_WORDS = 32 };
+__device__ __forceinline__ unsigned du_clock() { return (unsigned)__builtin_amdgcn_s_memtime(); }
+// (pwbase: LDS float index of the workgroup's 4 x DPW_WORDS words, or -1; every wave clears its own words)
+__device__ __forceinline__ void du_calibrate(DCtx& g, int pwbase, int wave, int lane) {
+    g.pw = -1; g.qs = 0u; g.lead = 0u;
+    if (pwbase < 0) return;
+    g.pw = pwbase + wave * DPW_WORDS;
+    if (lane < DPW_WORDS) lds[g.pw + lane] = 0.f;
+    const unsigned t0 = du_clock();
+    __builtin_amdgcn_s_sleep(127);
+    const unsigned dt = du_clock() - t0;                       // ticks per 127 x 64 clocks
+    g.qs = dt ? (127u << 16) / dt : 0u;
+    g.lead = dt >> 3;                                          // ~1 000 clocks
+    if (!g.qs || !g.lead) g.pw = -1;
+}
+// this wave has just published its output for tile t (or passed the point that stands for it): the intervals of its next waits count from here
+__device__ __forceinline__ void du_anchor(DCtx& g, int t, int lane) {
+    if (g.pw < 0) return;
+    const unsigned now = du_clock();
+    if (lane == 0) lds[g.pw + DPW_ANCHOR + t] = __uint_as_float(now);
+}
+struct DWait { unsigned anchor, d1; int at; };
+__device__ __forceinline__ DWait du_wait_begin(DCtx& g, int kind, int t) {
+    DWait w; w.anchor = 0u; w.d1 = 0u; w.at = -1;
+    if (g.pw < 0 || kind < 0) return w;
+    w.at = g.pw + 2 * (kind * 4 + t);
+    w.anchor = __builtin_amdgcn_readfirstlane(__float_as_uint(lds[g.pw + DPW_ANCHOR + t]));
+    w.d1 = __builtin_amdgcn_readfirstlane(__float_as_uint(lds[w.at]));
+    const unsigned d2 = __builtin_amdgcn_readfirstlane(__float_as_uint(lds[w.at + 1]));
+    const unsigned d = w.d1 < d2 ? w.d1 : d2;
+    if (w.anchor != 0u && d >= 4u * g.lead) {                  // (shorter intervals are hops: not predictable to a poll's length)
+        const int ahead = (int)(w.anchor + d - (d >> 2) - g.lead - du_clock());        // ticks until the nap should end
+        if (ahead > 0 && (unsigned)ahead < d) {
+            const unsigned q = (unsigned)(((unsigned long long)(unsigned)ahead * g.qs) >> 16);
+            for (unsigned i = 0; i < (q >> 2); ++i) __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    return w;
+}
+__device__ __forceinline__ void du_wait_end(DCtx& g, const DWait& w, int lane) {
+    if (w.at < 0) return;
+    const unsigned now = du_clock();
+    if (lane == 0) { lds[w.at] = __uint_as_float(w.anchor ? now - w.anchor : 0u); lds[w.at + 1] = __uint_as_float(w.d1); }
+}
 
 __device__ __forceinline__ u32x4 du_ld(const DCtx& g, int vbyte, int sbyte) {
     return __builtin_amdgcn_raw_buffer_load_b128(g.xrs, vbyte, sbyte, 16 /*sc1: not through the CU's L1*/);
@@ -257,19 +343,24 @@ __device__ __forceinline__ bool du_spin(DCtx& g, int& spins, unsigned what) {
 // a fragment crosses L2 -> CU once per workgroup (streamed by every wave for itself -- the first form of this kernel -- the
 // 32 waves of a group pulled 4 MB per GEMM and XCD through L2 and every stream ran at the L2 latency: 190 cycles per k-block).
 template <int NF>
-__device__ __forceinline__ void du_gather(DCtx& g, int wave, int lane, int sbyte, int l4, unsigned what) {
+__device__ __forceinline__ void du_gather(DCtx& g, int wave, int lane, int sbyte, int l4, unsigned what, int pkind = -1, int ptile = 0) {
     constexpr int NFW = (NF + 3) / 4;
     u32x4 v[NFW];
     int spins = 0;
+    const DWait tw = du_wait_begin(g, pkind, ptile);
     while (true) {
-        bool bad = false;
 #pragma unroll
         for (int u = 0; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) v[u] = du_ld(g, lane * 16, sbyte + (wave + 4 * u) * 1024);
+        // (a failed poll looks at ONE fragment: 4 vector instructions instead of 4 per fragment in the way of the co-resident role's MFMAs)
+        bool bad = du_bad(v[0]);
+        if (!__any(bad)) {
 #pragma unroll
-        for (int u = 0; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) bad |= du_bad(v[u]);
-        if (!__any(bad)) break;
+            for (int u = 1; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) bad |= du_bad(v[u]);
+            if (!__any(bad)) break;
+        }
         if (du_spin(g, spins, what)) break;
     }
+    du_wait_end(g, tw, lane);
     float4* L4 = reinterpret_cast<float4*>(lds);
 #pragma unroll
     for (int u = 0; u < NFW; ++u)
@@ -278,19 +369,23 @@ __device__ __forceinline__ void du_gather(DCtx& g, int wave, int lane, int sbyte
 
 // The same with the NF fragments split over TWO waves (which = 0 / 1 takes the even / odd ones).
 template <int NF>
-__device__ __forceinline__ void du_gather2(DCtx& g, int which, int lane, int sbyte, int l4, unsigned what) {
+__device__ __forceinline__ void du_gather2(DCtx& g, int which, int lane, int sbyte, int l4, unsigned what, int pkind = -1, int ptile = 0) {
     constexpr int NFW = (NF + 1) / 2;
     u32x4 v[NFW];
     int spins = 0;
+    const DWait tw = du_wait_begin(g, pkind, ptile);
     while (true) {
-        bool bad = false;
 #pragma unroll
         for (int u = 0; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) v[u] = du_ld(g, lane * 16, sbyte + (which + 2 * u) * 1024);
+        bool bad = du_bad(v[0]);
+        if (!__any(bad)) {
 #pragma unroll
-        for (int u = 0; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) bad |= du_bad(v[u]);
-        if (!__any(bad)) break;
+            for (int u = 1; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) bad |= du_bad(v[u]);
+            if (!__any(bad)) break;
+        }
         if (du_spin(g, spins, what)) break;
     }
+    du_wait_end(g, tw, lane);
     float4* L4 = reinterpret_cast<float4*>(lds);
 #pragma unroll
     for (int u = 0; u < NFW; ++u)
@@ -329,6 +424,10 @@ __device__ __forceinline__ f32x4 du_gemm_lds(const f32x4 (&W)[NKB], int b4, Mid 
     DU_FENCE2(a0, a1);
     return a0 + a1;
 }
+
+// (Tried in round 5 and taken out: the fine form's P2 / P3 with the wave's sixteen fragments taken STRAIGHT from L2 into registers -- no staging
+// buffer, no barrier, the product starting on the first four while the other twelve arrive.  n = 128: 2.47 ms against 2.35 staged, n = 256 equal:
+// the twelve follow their request by a full round trip, which the first 16 MFMAs do not cover, and every fragment crosses L2 -> CU twice.)
 
 // Diagnostic build only (-DNOCF_STAMPS): per-wave shader-clock timeline of ONE evaluation of group 0 / member 0 (both roles):
 // tools/duo_timeline.py.  The production library contains no stamp.
@@ -374,7 +473,8 @@ __device__ __forceinline__ DXPar du_x_params(const DevProb& pb, int PD) {
 // [2 N entries][4 floats] (entry i and i + N are the same agent, the fourth float is padding): the partner (a + j) mod N is entry
 // a + j -- no wrap, one ds_read_b128 per partner, consecutive lanes read consecutive entries.  Half 0 adds the obstacle terms.
 // Straight-line selects, no per-pair branches; every unordered pair is counted once.  Returns this lane's partial sums.
-template <int PD>
+// (quarters: the partner range in FOUR parts, `half` = 0..3 -- the fine form has one own sample per member and gives it all four waves)
+template <int PD, bool QUARTERS = false>
 __device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, int x4 /* LDS float4 index of the sample's entries */, int lane, int half,
                                           float& qacc, float& wacc) {
     const int N = xp.N;
@@ -397,7 +497,8 @@ __device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, in
         }
         return;
     }
-    const int jlo = half ? xp.Jh + 1 : 1, jhi = half ? xp.JJ : xp.Jh;           // partners jlo..jhi (inclusive)
+    int jlo = half ? xp.Jh + 1 : 1, jhi = half ? xp.JJ : xp.Jh;                 // partners jlo..jhi (inclusive)
+    if (QUARTERS) { const int Jq = (xp.JJ + 3) >> 2; jlo = half * Jq + 1; jhi = (half + 1) * Jq < xp.JJ ? (half + 1) * Jq : xp.JJ; }
     const bool actlow = act & (a < (N >> 1));                                   // the opposite agent (even N) counts from the lower half only
     constexpr int XW = 5;                                   // partners per round (their LDS reads are in flight together)
     for (int j = jlo; j <= jhi; j += XW) {
@@ -428,11 +529,11 @@ __device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, in
 // byte offsets of the exchange kinds inside a group's area (functions of NT), all pinned in scalar registers by the kernel
 struct DXOff { int S, U, T, V, G, Q, P; };
 // (bwd: the adjoint's layout -- the Q area holds the physics term of two own samples per member, 2 x 160 floats, instead of 2 x 2 scalars)
-__host__ __device__ inline long duo_x_layout(int NT, DXOff* o, bool bwd = false) {
+__host__ __device__ inline long duo_x_layout(int NT, DXOff* o, bool bwd = false, int G = DU_G) {
     long x = 0;
     auto take = [&](long nfl) { const long at = x; x += (nfl + 63) / 64 * 64; return at; };
     const long s = take(2L * NT * DU_KBD * 256), u = take(2L * NT * DU_KBM * 256), t = take(2L * NT * DU_KBM * 256), v = take(2L * NT * DU_KBM * 256);
-    const long gg = take(2L * NT * DU_G * DU_KBD * 256), q = take(3L * NT * DU_G * (bwd ? 320 : 4)), p = take((long)NT * DU_G * 4 * 16);
+    const long gg = take(2L * NT * G * DU_KBD * 256), q = take(3L * NT * G * (bwd ? 320 : 4)), p = take((long)NT * DU_G * 4 * 16);
     if (o) { o->S = (int)(s * 4); o->U = (int)(u * 4); o->T = (int)(t * 4); o->V = (int)(v * 4); o->G = (int)(gg * 4); o->Q = (int)(q * 4); o->P = (int)(p * 4); }
     return x;                                      // floats per group
 }
@@ -441,8 +542,14 @@ struct DuoRun { long row0, n_total; };             // rows of this launch inside
 
 // REC: the training variant also stores every stage input (RollArgs::sAll); ZF: intermediates (trajectories and controls, one more
 // evaluation per step); the plain evaluation variant carries no trace of either
-template <int PD, bool REC, bool ZF>
+template <int PD, bool REC, bool ZF, int GM = DU_G>
 __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __restrict__ dpp, DevProb pb, float* ws, RollArgs ra, DuoRun rr) {
+    typedef DuoCfg<GM> CF;
+    constexpr int G = CF::G, MTM = CF::MTM, KS = CF::KS, SPM = CF::SPM, KBW = CF::KBW, KB1 = CF::KB1, WPG = CF::WPG, HPM = CF::HPM;
+    // LDS of the fine form: the waves' partial sums [4 waves][64 lanes][4] (role A: in front of the per-sample blocks; role B: in the half of
+    // the K4 region that its half-sized image leaves free)
+    constexpr int DAPX = DA_T, DAPW = DA_T + (KS > 1 ? 1024 : 0), DAT = DAPW + 4 * DPW_WORDS, DBPX = DB_K4 + DU_KBD * MTM * 256, DBPW = DB_END;
+    static_assert(KS == 1 || DBPX + 1024 <= DB_VEC, "role B's partial sums must fit behind the K4 image");
     const DuoPlan& dp = *dpp;
     const int bid = blockIdx.x;
     const int jb = bid >> 3;
@@ -455,14 +562,14 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     // its XCD slot; when all workgroups of the slot have arrived and #CUs x 2 = #workgroups (every CU holds exactly two), rank r is
     // (group r / 8 of the slot, member r % 8), the first-arrived workgroup takes role A.  Otherwise the slot keeps the static map.
     // Placement decides speed only: results do not depend on which workgroup computes what.
-    int group = (bid & 7) + 8 * (jb >> 4);
-    int within = jb & 15;
-    int member = (dp.mapmode & 1) ? (within >> 1) : (within & 7);
-    int role = (dp.mapmode & 1) ? (within & 1) : (within >> 3);
+    int group = (bid & 7) + 8 * (jb / WPG);
+    int within = jb % WPG;
+    int member = (dp.mapmode & 1) ? (within >> 1) : (within % G);
+    int role = (dp.mapmode & 1) ? (within & 1) : (within / G);
     if (dp.mapmode & 2) {
         if (tid == 0) {
             const int xsl = bid & 7;
-            const int nwg = xsl < dp.ngroups ? 16 * ((dp.ngroups - xsl + 7) / 8) : 0;       // workgroups of this slot that have work
+            const int nwg = xsl < dp.ngroups ? WPG * ((dp.ngroups - xsl + 7) / 8) : 0;      // workgroups of this slot that have work
             unsigned* cen = reinterpret_cast<unsigned*>(ws) + dp.oCen + xsl * 520;      // [0] arrived, [1] CUs seen, [8..263] workgroups per CU, [264..519] rank + 1 per CU
             unsigned hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -498,8 +605,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         __syncthreads();
         if (lds[0] != 0.f) {
             const int rank = (int)lds[1];
-            group = (bid & 7) + 8 * (rank >> 3);
-            member = rank & 7;
+            group = (bid & 7) + 8 * (rank / G);
+            member = rank % G;
             role = (int)lds[2];
             within = member * 2 + role;
         }
@@ -508,46 +615,49 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     if (group >= dp.ngroups) return;
     const int lane = tid & 63, slot = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ft = KS > 1 ? wave % MTM : wave, kh = KS > 1 ? wave / MTM : 0;                 // this wave's feature tile of the member, its part of the contraction
     int NT = dp.NT; DU_PIN(NT);
     const int d = dp.d;
     const float hN = dp.hN;
     DXOff xo;
-    (void)duo_x_layout(NT, &xo);
+    (void)duo_x_layout(NT, &xo, false, G);
     int xS = xo.S, xU = xo.U, xT = xo.T, xV = xo.V, xG = xo.G, xQ = xo.Q, xP = xo.P;
     DU_PIN(xS); DU_PIN(xU); DU_PIN(xT); DU_PIN(xV); DU_PIN(xG); DU_PIN(xQ); DU_PIN(xP);
     DCtx g;
     g.xrs = __builtin_amdgcn_make_buffer_rsrc(ws + dp.oX + (long)group * dp.xStride, 0, (int)(dp.xStride * 4), 0x00020000);
     g.err = reinterpret_cast<unsigned*>(ws) + dp.oErr;
     g.fast = 0; g.spin_max = dp.spin_max; g.dead = false; g.slow = NT > 1;
+    g.pw = -1; g.qs = 0u; g.lead = 0u;                          // (set per role below: the slots live in that role's LDS carve)
+    g.udelay = (dp.dbg >> 8) & 15;
     const float4* ws4 = reinterpret_cast<const float4*>(ws);
     float4* L4 = reinterpret_cast<float4*>(lds);
     const int vb = lane * 16;                                   // this lane's 16 bytes of a fragment
 #ifdef NOCF_STAMPS
     unsigned long long* tlp = nullptr;
     const int e_probe = (ra.nt / 2) * ((ra.stepper == NOCF_RK4) ? 4 : 1) + 2;
-#define DTL_EPOCH(e_) tlp = (ra.stamps && group == 0 && (e_) == e_probe) ? ra.stamps + ((member * 2 + role) * 4 + wave) * 128 : nullptr
+#define DTL_EPOCH(e_) tlp = (ra.stamps && group == 0 && member < DU_G && (e_) == e_probe) ? ra.stamps + ((member * 2 + role) * 4 + wave) * 128 : nullptr
 #else
 #define DTL_EPOCH(e_) do { } while (0)
 #endif
 
     // ---- the resident weight slice: 128 AccVGPRs per lane, loaded once (role A: K1[H_c,:], role B: K1[:,H_c]^T)
-    f32x4 W[DU_KBM];
+    f32x4 W[KBW];
     {
-        const long bw = (role ? dp.oW3 : dp.oW2) + (long)(member * 4 + wave) * DU_KBM * 64 + lane;
+        const long bw = (role ? dp.oW3 : dp.oW2) + (long)(member * 4 + wave) * KBW * 64 + lane;
 #pragma unroll
-        for (int kb = 0; kb < DU_KBM; ++kb) { const float4 a = ws4[bw + kb * 64]; W[kb] = (f32x4){a.x, a.y, a.z, a.w}; }
+        for (int kb = 0; kb < KBW; ++kb) { const float4 a = ws4[bw + kb * 64]; W[kb] = (f32x4){a.x, a.y, a.z, a.w}; }
     }
     // ---- where do the 16 workgroups of my group run?  (same-XCD groups keep the exchange in that XCD's L2)
     if (dp.fast && wave == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc = (xcc & 0xfu) + 1u;
-        unsigned* tab = reinterpret_cast<unsigned*>(ws) + dp.oXcc + (long)group * 16;
+        unsigned* tab = reinterpret_cast<unsigned*>(ws) + dp.oXcc + (long)group * WPG;
         if (lane == 0) __hip_atomic_store(tab + within, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         unsigned v = 0;
         while (true) {
-            v = __hip_atomic_load(tab + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(tab + (lane & (WPG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(v != 0u)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > dp.spin_max) { if (lane == 0) atomicExch(g.err, 0x3000u + DUK_XCC); break; }
@@ -560,88 +670,93 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 
     const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
     const long rowg = (long)group * 16 * NT;                    // first row (of this launch) of the group
-    auto own_row = [&](int t, int j) -> long { return rowg + 16 * t + 2 * member + j; };
+    auto own_row = [&](int t, int j) -> long { return rowg + 16 * t + SPM * member + j; };
 
     if (role == 0) {
         // =====================================================================================================
         // role A: own (partial gradients -> RK update -> next stage state), P1, P2
         // =====================================================================================================
         // P1's A operand: this wave's 16 rows of K0, 40 VGPRs (the AccVGPR half of the 256-register budget is the K1 slice)
-        f32x4 K0r[DU_KBD];
+        f32x4 K0r[KB1];
         {
-            const long b1 = dp.oK1 + (long)(member * 4 + wave) * DU_KBD * 64 + lane;
+            const long b1 = dp.oK1 + (long)(member * 4 + wave) * KB1 * 64 + lane;
 #pragma unroll
-            for (int kb = 0; kb < DU_KBD; ++kb) { const float4 a = ws4[b1 + kb * 64]; K0r[kb] = (f32x4){a.x, a.y, a.z, a.w}; }
+            for (int kb = 0; kb < KB1; ++kb) { const float4 a = ws4[b1 + kb * 64]; K0r[kb] = (f32x4){a.x, a.y, a.z, a.w}; }
         }
         for (int i = tid; i < 16 * DU_DP; i += 256) lds[DA_A + i] = ws[dp.oA + i];
         if (tid < DU_DP) lds[DA_CW + tid] = ws[dp.oCW + tid];
-        if (tid < 192) lds[DA_VEC + tid] = ws[dp.oVec + (tid >> 6) * 64 * DU_G + member * 64 + (tid & 63)];
-        for (int i = tid; i < 2 * NT * DS_STRIDE; i += 256) lds[DA_T + i] = 0.f;
+        if (tid < 192 && (tid & 63) < HPM) lds[DA_VEC + tid] = ws[dp.oVec + (tid >> 6) * 64 * DU_G + member * HPM + (tid & 63)];
+        for (int i = tid; i < SPM * NT * DS_STRIDE; i += 256) lds[DAT + i] = 0.f;
+        du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DAPW, wave, lane);     // (one tile per group: measured, see DCtx; dbg bit 16 forces it on)
         __syncthreads();
-        for (int i = tid; i < 2 * NT * DU_DP; i += 256) {
+        for (int i = tid; i < SPM * NT * DU_DP; i += 256) {
             const int s = i / DU_DP, c = i - s * DU_DP;
-            long row = own_row(s >> 1, s & 1); if (row >= ra.n) row = ra.n - 1;
+            long row = own_row(s / SPM, s % SPM); if (row >= ra.n) row = ra.n - 1;
             const float v = (c < d) ? ra.x[row * d + c] : 0.f;
-            lds[DA_T + s * DS_STRIDE + DS_Z0 + c] = v;
-            lds[DA_T + s * DS_STRIDE + DS_XS + c] = (c == d) ? (float)ra.t0 : v;
+            lds[DAT + s * DS_STRIDE + DS_Z0 + c] = v;
+            lds[DAT + s * DS_STRIDE + DS_XS + c] = (c == d) ? (float)ra.t0 : v;
         }
         __syncthreads();
         const float cAlphQ = (float)pb.alphQ, cAlphW = (float)pb.alphW;
         const bool cWantW = want_W(pb);
         const float c16 = (float)(1.0 / 6.0), c26 = (float)(2.0 / 6.0);
         int rA = dp.r; DU_PIN(rA);
-        // Owner units are SAMPLES: own sample s = 2 t + j (sample 2 member + j of tile t) belongs to wave s & 3; lane l < 40 of that
+        // Owner units are SAMPLES: own sample s = SPM t + j (sample SPM member + j of tile t) belongs to wave s & 3; lane l < 40 of that
         // wave keeps the piece dims 4 l .. 4 l + 3 = (dim tile mt = l / 4, slot sl = l % 4) of the sample.
         const bool pact = lane < 40;
         const int pmt = lane >> 2, psl = lane & 3, pi = pact ? 4 * lane : 0;
         const int pd_lane = d >> 2, pd_e = d & 3;                     // where g[d] = dPhi/dt sits
 
         // Requests for the 8 members' partial gradients of own sample s (evaluation parity parG): this lane's 16 bytes of each.
-        auto g_request = [&](int s, int parG, u32x4 (&pv)[DU_G]) {
-            const int t = s >> 1, j = s & 1;
+        auto g_request = [&](int s, int parG, u32x4 (&pv)[G]) {
+            const int t = s / SPM, j = s % SPM;
             // (per-lane parts of an address go into the VECTOR offset: a per-lane scalar offset makes hipcc serialise the access
             // in a waterfall loop over its distinct values -- 80 iterations for these 8 loads, 11 k cycles in the first version)
-            const int lp = (psl * 16 + 2 * member + j) * 16 + (pact ? pmt : 0) * 1024;
-            const int sb = xG + ((parG * NT + t) * DU_G * DU_KBD) * 1024;
+            const int lp = (psl * 16 + SPM * member + j) * 16 + (pact ? pmt : 0) * 1024;
+            const int sb = xG + ((parG * NT + t) * G * DU_KBD) * 1024;
 #pragma unroll
-            for (int mem = 0; mem < DU_G; ++mem) pv[mem] = du_ld(g, lp, sb + mem * DU_KBD * 1024);
+            for (int mem = 0; mem < G; ++mem) pv[mem] = du_ld(g, lp, sb + mem * DU_KBD * 1024);
         };
         // g of own sample s: fixed-order sum of the partials + A^T (A s) + c.  have: pv already holds the answer of an earlier request
         // (issued in front of the previous tile's P2, one L2 round trip off the critical path); it is used if it shows no sentinel.
-        auto gather_g = [&](int s, int parG, bool have, u32x4 (&pv)[DU_G]) -> f32x4 {
+        auto gather_g = [&](int s, int parG, bool have, u32x4 (&pv)[G]) -> f32x4 {
             int spins = 0;
+            const DWait tw = du_wait_begin(g, DPW_G, s / SPM);
             while (true) {
                 if (!have) g_request(s, parG, pv);
                 have = false;
-                bool bad = false;
+                bool bad = du_bad(pv[0]);
+                if (!__any(bad && pact)) {
 #pragma unroll
-                for (int mem = 0; mem < DU_G; ++mem) bad |= du_bad(pv[mem]);
-                if (!__any(bad && pact)) break;
+                    for (int mem = 1; mem < G; ++mem) bad |= du_bad(pv[mem]);
+                    if (!__any(bad && pact)) break;
+                }
                 if (du_spin(g, spins, DUK_G)) break;
             }
+            du_wait_end(g, tw, lane);
             f32x4 gs = du_f(pv[0]);
 #pragma unroll
-            for (int mem = 1; mem < DU_G; ++mem) gs += du_f(pv[mem]);
-            const float4 z = L4[(DA_T + s * DS_STRIDE + DS_AZC + pi) >> 2];
+            for (int mem = 1; mem < G; ++mem) gs += du_f(pv[mem]);
+            const float4 z = L4[(DAT + s * DS_STRIDE + DS_AZC + pi) >> 2];
             gs += (f32x4){z.x, z.y, z.z, z.w};
             return gs;
         };
 
         // the owner's step, state part: gradient of evaluation e-1 -> RK update -> stage state of evaluation e published.
         // Leaves this lane's share of sum p^2 (q0) and its candidate for dPhi/dt (gdv) for the cost part.
-        auto own_state = [&](int s, int e, float hs, int pst, int pk, float t_pub, bool have, u32x4 (&pv)[DU_G]) {
-            const int t = s >> 1, j = s & 1;
+        auto own_state = [&](int s, int e, float hs, int pst, int pk, float t_pub, bool have, u32x4 (&pv)[G]) {
+            const int t = s / SPM, j = s % SPM;
             const int parG = (e - 1) & 1, parS = e & 1;
             const bool rk_last = (pst == nstage - 1);
             const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
             const float rk_wx = (pst < 2) ? 0.5f : 1.f;
-            const int sbase = DA_T + s * DS_STRIDE;
+            const int sbase = DAT + s * DS_STRIDE;
             DTL(40 * t + 0);
             const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2];      // (in flight while the partials are polled)
             if (!have) g_request(s, parG, pv);
             unsigned qa = 0, qb = 0;
             if (pst != nstage) {   // the cost scalars of this sample ride along (consumed by own_costs, behind P2): their round trip is off the critical path
-                const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((e - 1) % 3) * NT + t) * DU_G + member) * 4 + 2 * j) * 4, 16);
+                const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((e - 1) % 3) * NT + t) * G + member) * 4 + 2 * j) * 4, 16);
                 qa = v2[0]; qb = v2[1];
             }
             const f32x4 gs = gather_g(s, parG, true, pv);
@@ -684,7 +799,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 < d) ra.zFull[((long)(pk + 1) * rr.n_total + orow) * (d + 4) + pi + e4] = zn[e4];
                     }
                 }
-                const int lp = (psl * 16 + 2 * member + j) * 16 + pmt * 1024;
+                const int lp = (psl * 16 + SPM * member + j) * 16 + pmt * 1024;
                 du_st(g, lp, xS + ((parS * NT + t) * DU_KBD) * 1024, xs);
                 du_st_sent(g, lp, xS + (((parS ^ 1) * NT + t) * DU_KBD) * 1024);
                 if (!pctrl) {
@@ -716,11 +831,11 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // ... cost part (off the critical path: it runs behind P1, while the u0 exchange travels): sum p^2, dPhi/dt, the x-only terms
         // from role B -> the four cost integrals of evaluation e-1
         auto own_costs = [&](int s, int e, float hs, int pst, int pk) {
-            const int t = s >> 1, j = s & 1;
+            const int t = s / SPM, j = s % SPM;
             const int parG = (e - 1) & 1;
             const bool rk_last = (pst == nstage - 1);
             const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
-            const int sbase = DA_T + s * DS_STRIDE;
+            const int sbase = DAT + s * DS_STRIDE;
             const float4 oc = L4[(sbase + DS_OC) >> 2];
             const float sp2 = oc.x, gt = oc.y;
             unsigned qa = __float_as_uint(oc.z), qb = __float_as_uint(oc.w);
@@ -728,7 +843,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
             float q_ = 0.f, w_ = 0.f;
             {
-                const int ob = xQ + (((((e - 1) % 3) * NT + t) * DU_G + member) * 4 + 2 * j) * 4;
+                const int ob = xQ + (((((e - 1) % 3) * NT + t) * G + member) * 4 + 2 * j) * 4;
                 int spins = 0;
                 while (true) {
                     if (!have) { const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, ob, 16); qa = v2[0]; qb = v2[1]; }
@@ -763,7 +878,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // z = A s and A^T z + c of own sample s at its CURRENT stage state (needed when the gradient of this evaluation arrives).
         // LDS reads in batches that are in flight together (a dependent read costs ~130 cycles when waited for alone).
         auto azc_step = [&](int s, bool fin) {
-            const int sbase = DA_T + s * DS_STRIDE;
+            const int sbase = DAT + s * DS_STRIDE;
             {
                 const int q = lane >> 2, part = lane & 3;            // row of A, quarter of the dims (10 float4 each)
                 const int ia = ((DA_A + q * DU_DP) >> 2) + part * 10, ix = ((sbase + DS_XS) >> 2) + part * 10;
@@ -810,11 +925,11 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         };
 
         // ---- evaluation 1: the stage states come straight from x
-        for (int s = wave; s < 2 * NT; s += 4) {
-            const int t = s >> 1, j = s & 1, sbase = DA_T + s * DS_STRIDE;
+        for (int s = wave; s < SPM * NT; s += 4) {
+            const int t = s / SPM, j = s % SPM, sbase = DAT + s * DS_STRIDE;
             if (pact) {
                 const float4 x4 = L4[(sbase + DS_XS + pi) >> 2];
-                du_st(g, (psl * 16 + 2 * member + j) * 16 + pmt * 1024, xS + ((1 * NT + t) * DU_KBD) * 1024, (f32x4){x4.x, x4.y, x4.z, x4.w});
+                du_st(g, (psl * 16 + SPM * member + j) * 16 + pmt * 1024, xS + ((1 * NT + t) * DU_KBD) * 1024, (f32x4){x4.x, x4.y, x4.z, x4.w});
             }
             if (REC && ra.sAll && own_row(t, j) < ra.n)
                 for (int i = lane; i <= d; i += 64) ra.sAll[(rr.row0 + own_row(t, j)) * (d + 1) + i] = lds[sbase + DS_XS + i];
@@ -828,7 +943,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         int e = 0;
         float p_hs = 0.f; int p_st = 0, p_k = 0;
         const int nsub = nstage + (ZF ? 1 : 0);             // evaluations per step: the RK stages (+ the control evaluation of intermediates)
-        u32x4 pf[DU_G];                                            // the 8 members' partial gradients of an own sample (this lane's 16 bytes of each)
+        u32x4 pf[G];                                               // the G members' partial gradients of an own sample (this lane's 16 bytes of each)
         for (int k = 0; k <= ra.nt; ++k) {
             const bool fin = (k == ra.nt);
             const double t1k = tk + ra.h;
@@ -843,7 +958,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const double te = fin ? ra.t1 : ((nstage == 1 || st == 0 || st == nstage) ? tk : (st == 3 ? tk + hsd : tk + hsd / 2));
                 // tile after tile: while this workgroup multiplies tile t, role B works on the tile before it
                 for (int t = 0; t < NT; ++t) {
-                    const int s0 = 2 * t, s1 = 2 * t + 1;
+                    const int s0 = SPM * t, s1 = SPM * t + SPM - 1;
                     const int sown = ((s0 & 3) == wave) ? s0 : (((s1 & 3) == wave) ? s1 : -1);      // this wave's own sample of the tile, if any
                     if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, false, pf);
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
@@ -851,27 +966,46 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // (the two waves that own nothing of this tile fetch the stage states: the owners have just stored theirs, and a load issued
                     // behind a store is not answered before the store has been acknowledged -- vmcnt retires in order -- which occasionally
                     // takes thousands of cycles that every member of the group then waits for: 5.54 -> 5.29 ms)
-                    if (e > 1) { if (sown < 0) du_gather2<DU_KBD>(g, (wave ^ (wave >> 1)) & 1, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S); }
-                    else du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
+                    if (e > 1) {
+                        if (SPM == 2) { if (sown < 0) du_gather2<DU_KBD>(g, (wave ^ (wave >> 1)) & 1, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t); }
+                        else { const int wh = ((wave - (t & 3)) & 3) - 1; if (wh >= 0 && wh < 2) du_gather2<DU_KBD>(g, wh, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t); }
+                    } else du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
                     __syncthreads();
                     DTL(40 * t + 5);
                     {
-                        float4 b0s;                                                // bias of this lane's 4 features 16 wave + 4 slot + e
-                        const f32x4 acc = du_gemm_lds<DU_KBD, false>(K0r, (DA_SF >> 2) + lane, [&](int kb) { if (kb == DU_KBD - 3) b0s = L4[(DA_VEC >> 2) + 4 * wave + slot]; });
+                        float4 b0s;                                                // bias of this lane's 4 features 16 mt + 4 slot + e
+                        f32x4 acc = du_gemm_lds<KB1, false>(K0r, (DA_SF >> 2) + kh * KB1 * 64 + lane, [&](int kb) {
+                            if (kb == KB1 - 3) b0s = L4[(DA_VEC >> 2) + 4 * ft + slot];
+                            if (KS > 1 && kb == 1) {
+                                // fine form: the slots of the previous evaluation are reset HERE (S of this evaluation is staged: every reader is
+                                // done), a whole product + hop earlier than in the default form: P2 is only 64 MFMAs long there and its vmcnt(0) in front
+                                // of the V store would wait for these acknowledgements (H1 is unchanged: that wait still lies between them and V)
+                                const int fr = (((par ^ 1) * NT + t) * DU_KBM + MTM * member + ft) * 1024;
+                                if (kh == 0) { du_st_sent(g, vb, xU + fr); du_st_sent(g, vb, xV + fr); } else du_st_sent(g, vb, xT + fr);
+                            }
+                        });
+                        if (KS > 1) {       // the two halves of the contraction meet (fixed order: lower + upper k-blocks)
+                            L4[(DAPX >> 2) + wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                            __syncthreads();
+                            const float4 o4 = L4[(DAPX >> 2) + (wave ^ MTM) * 64 + lane];
+                            const f32x4 ot = {o4.x, o4.y, o4.z, o4.w};
+                            acc = kh ? ot + acc : acc + ot;
+                        }
                         DTL(40 * t + 6);
                         const float b0v[4] = {b0s.x, b0s.y, b0s.z, b0s.w};
                         f32x4 sg, th;
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) { float s_, t_; act_pair(acc[e4] + b0v[e4], s_, t_); sg[e4] = s_; th[e4] = t_; }
-                        const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
-                        du_st(g, vb, xU + fo, sg);
-                        du_st(g, vb, xT + fo, th);
+                        const int fo = ((par * NT + t) * DU_KBM + MTM * member + ft) * 1024;
+                        // (fine form: both waves of a feature tile hold o; one publishes sigma(o), the other tanh(o))
+                        if (KS == 1 || kh == 0) du_st(g, vb, xU + fo, sg);
+                        if (KS == 1 || kh == 1) du_st(g, vb, xT + fo, th);
                         if (REC && ra.act && (!fin || ra.tapeSc)) {    // activation record: 4 features of sample lane & 15 (64-byte runs per sample)
                             const long rw = rowg + 16 * t + (lane & 15);
                             if (rw < ra.n) {
-                                float* dst = ra.act + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G) + 64 * member + 16 * wave + 4 * slot;
-                                *reinterpret_cast<float4*>(dst) = make_float4(sg[0], sg[1], sg[2], sg[3]);
-                                *reinterpret_cast<float4*>(dst + ra.actRows * (64 * DU_G)) = make_float4(th[0], th[1], th[2], th[3]);
+                                float* dst = ra.act + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G) + HPM * member + 16 * ft + 4 * slot;
+                                if (KS == 1 || kh == 0) *reinterpret_cast<float4*>(dst) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+                                if (KS == 1 || kh == 1) *reinterpret_cast<float4*>(dst + ra.actRows * (64 * DU_G)) = make_float4(th[0], th[1], th[2], th[3]);
                             }
                         }
                     }
@@ -881,6 +1015,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
 #endif
                     DTL(40 * t + 8);
                     // ================= P2: q = K1[H_c,:] u0 + b1 ; v = tanh(q) . w =================
+                    // (the members of a group finish P1 within a few hundred clocks of each other, and a wave arrives here right behind its own U
+                    // store: a poll issued at once reaches L2 before the slowest member's fragment and costs a whole second round trip)
+                    for (int i = 0; i < g.udelay; ++i) __builtin_amdgcn_s_sleep(1);
                     du_gather<DU_KBM>(g, wave, lane, xU + ((par * NT + t) * DU_KBM) * 1024, DA_UF >> 2, DUK_U);
                     __syncthreads();
                     DTL(40 * t + 10);
@@ -888,15 +1025,22 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         // the slots of the previous evaluation (every reader is done: S of this evaluation exists).  Here, not in the P1
                         // epilogue: no load of this wave waits behind them, and the GEMM covers their acknowledgement (V one phase early:
                         // header, H1)
-                        const int fr = (((par ^ 1) * NT + t) * DU_KBM + 4 * member + wave) * 1024;
+                        const int fr = (((par ^ 1) * NT + t) * DU_KBM + MTM * member + ft) * 1024;
                         float4 b1s, wvs;
                         auto resets = [&](int kb) {
-                            if (kb == 1) { du_st_sent(g, vb, xU + fr); du_st_sent(g, vb, xT + fr); du_st_sent(g, vb, xV + fr); }
-                            if (kb == DU_KBM - 3) { b1s = L4[((DA_VEC + 64) >> 2) + 4 * wave + slot]; wvs = L4[((DA_VEC + 128) >> 2) + 4 * wave + slot]; }
+                            if (KS == 1 && kb == 1) { du_st_sent(g, vb, xU + fr); du_st_sent(g, vb, xT + fr); du_st_sent(g, vb, xV + fr); }      // (fine form: in P1)
+                            if (kb == KBW - 3) { b1s = L4[((DA_VEC + 64) >> 2) + 4 * ft + slot]; wvs = L4[((DA_VEC + 128) >> 2) + 4 * ft + slot]; }
                         };
-                        const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DA_UF >> 2) + lane, resets);
+                        f32x4 acc = du_gemm_lds<KBW, true>(W, (DA_UF >> 2) + kh * KBW * 64 + lane, resets);
                         DTL(40 * t + 11);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the resets are acknowledged -- long ago -- before V is stored: header, H1)
+                        if (KS > 1) {       // (the barrier also orders the tanh(o) reset of the partner wave, acknowledged above, before this wave's V store)
+                            L4[(DAPX >> 2) + wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                            __syncthreads();
+                            const float4 o4 = L4[(DAPX >> 2) + (wave ^ MTM) * 64 + lane];
+                            const f32x4 ot = {o4.x, o4.y, o4.z, o4.w};
+                            acc = kh ? ot + acc : acc + ot;
+                        }
                         const float b1v[4] = {b1s.x, b1s.y, b1s.z, b1s.w}, wv[4] = {wvs.x, wvs.y, wvs.z, wvs.w};
                         f32x4 v;
 #ifdef NOCF_STAMPS
@@ -910,29 +1054,30 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         asm volatile("" : "+v"(v));
                         DTL(40 * t + 17);
 #endif
-                        du_st(g, vb, xV + ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024, v);
+                        if (KS == 1 || kh == 0) du_st(g, vb, xV + ((par * NT + t) * DU_KBM + MTM * member + ft) * 1024, v);
+                        du_anchor(g, t, lane);                  // (predictive waiting: this wave's next waits for tile t count from here)
                         DTL(40 * t + 12);
-                        if (REC && ra.act && (!fin || ra.tapeSc)) {    // activation record: tanh(q)
+                        if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 0)) {    // activation record: tanh(q)
                             const long rw = rowg + 16 * t + (lane & 15);
                             if (rw < ra.n)
                                 *reinterpret_cast<float4*>(ra.act + 2 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
-                                                           + 64 * member + 16 * wave + 4 * slot) = make_float4(tq[0], tq[1], tq[2], tq[3]);
+                                                           + HPM * member + 16 * ft + 4 * slot) = make_float4(tq[0], tq[1], tq[2], tq[3]);
                         }
-                        if (fin) {
+                        if (fin && (KS == 1 || kh == 1)) {     // (fine form: the wave that does not publish v takes the value's part)
                             // w . u_1 = w . (u_0 + hN sigma(q)) over this wave's 16 features (src/Phi.py:91-96): own u_0 fragment from the staged tile
-                            const float4 u4 = L4[(DA_UF >> 2) + (4 * member + wave) * 64 + lane];
+                            const float4 u4 = L4[(DA_UF >> 2) + (MTM * member + ft) * 64 + lane];
                             const float u0[4] = {u4.x, u4.y, u4.z, u4.w};
                             float pr = 0.f, u1[4];
 #pragma unroll
                             for (int e4 = 0; e4 < 4; ++e4) { u1[e4] = u0[e4] + hN * sigma_act(acc[e4] + b1v[e4]); pr += wv[e4] * u1[e4]; }
                             if (REC && ra.tapeU1) {                    // tape: u_1 of the terminal evaluation (the value's dw row)
                                 const long rw = rowg + 16 * t + (lane & 15);
-                                if (rw < ra.n) *reinterpret_cast<float4*>(ra.tapeU1 + (rr.row0 + rw) * (64 * DU_G) + 64 * member + 16 * wave + 4 * slot) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                                if (rw < ra.n) *reinterpret_cast<float4*>(ra.tapeU1 + (rr.row0 + rw) * (64 * DU_G) + HPM * member + 16 * ft + 4 * slot) = make_float4(u1[0], u1[1], u1[2], u1[3]);
                             }
                             pr += __shfl_xor(pr, 16); pr += __shfl_xor(pr, 32);
                             if (lane < 16) {
                                 const unsigned pu = __float_as_uint(pr);
-                                const int off = xP + (((t * DU_G + member) * 4 + wave) * 16 + lane) * 4;
+                                const int off = xP + (((t * G + member) * MTM + ft) * 16 + lane) * 4;
                                 if (g.fast) __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 0);
                                 else __builtin_amdgcn_raw_buffer_store_b32(pu, g.xrs, off, 0, 16);
                             }
@@ -954,8 +1099,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             tk += ra.h;
         }
         // ---- terminal costs of the own samples (src/OCflow.py:58-76): gradient and Phi of the terminal evaluation
-        for (int s = wave; s < 2 * NT; s += 4) {
-            const int t = s >> 1, j = s & 1, sbase = DA_T + s * DS_STRIDE;
+        for (int s = wave; s < SPM * NT; s += 4) {
+            const int t = s / SPM, j = s % SPM, sbase = DAT + s * DS_STRIDE;
             const f32x4 gs = gather_g(s, e & 1, false, pf);
             float r2 = 0.f, hg = 0.f;
             if (pact) {
@@ -965,12 +1110,12 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 < d) { const float res = zz[e4] - pb.xtarget[pi + e4]; r2 += res * res; hg += fabsf(gs[e4] - ra.a0 * res); }
             }
             const float cG = 0.5f * sum64(r2), hj = sum64(hg);
-            // w . u_1: the 8 members x 4 waves partials of this sample (lanes 0..31: member lane / 4, wave lane % 4)
+            // w . u_1: the G members x MTM feature tiles = 32 partials of this sample (lanes 0..31)
             float ph;
             {
                 unsigned u = 0;
                 int spins = 0;
-                const int off = xP + ((t * DU_G * 4 + (lane & 31)) * 16 + 2 * member + j) * 4;
+                const int off = xP + ((t * G * MTM + (lane & 31)) * 16 + SPM * member + j) * 4;
                 while (true) {
                     u = __builtin_amdgcn_raw_buffer_load_b32(g.xrs, off, 0, 16);
                     if (!__any(u == DU_SENT)) break;
@@ -1010,8 +1155,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // =====================================================================================================
         // role B: x-only cost terms, P3, P4
         // =====================================================================================================
-        for (int i = tid; i < DU_KBD * 4 * 64; i += 256) L4[(DB_K4 >> 2) + i] = ws4[dp.oK4 + (long)member * DU_KBD * 4 * 64 + i];
-        if (tid < 64) lds[DB_VEC + tid] = ws[dp.oVec + 2 * 64 * DU_G + member * 64 + tid];
+        for (int i = tid; i < DU_KBD * MTM * 64; i += 256) L4[(DB_K4 >> 2) + i] = ws4[dp.oK4 + (long)member * DU_KBD * MTM * 64 + i];
+        if (tid < HPM) lds[DB_VEC + tid] = ws[dp.oVec + 2 * 64 * DU_G + member * HPM + tid];
+        du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DBPW, wave, lane);
         __syncthreads();
         const DXPar xp = du_x_params(pb, PD);
         const int nsub = nstage + (ZF ? 1 : 0);
@@ -1027,9 +1173,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 DTL(40 * t + 20);
                 if (stage) {
                     // ================= x-only cost terms of the own samples of tile t at the state of evaluation e =================
-                    if (wave < 2) {                                     // 80 pieces of 16 B: dims 4 l .. 4 l + 3 of own sample j
-                        const int p = tid < 80 ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, mt = r_ >> 2, sl = r_ & 3;
-                        const int off = xS + ((par * NT + t) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16;
+                    if (wave < SPM) {                                   // 40 SPM pieces of 16 B: dims 4 l .. 4 l + 3 of own sample j
+                        const int p = tid < 40 * SPM ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, pmt = r_ >> 2, sl = r_ & 3;
+                        const int off = xS + ((par * NT + t) * DU_KBD + pmt) * 1024 + (sl * 16 + SPM * member + j) * 16;
                         u32x4 v = spf;
                         bool have = spf_t == t;                         // requested before the previous tile's P4 stores (see there)
                         int spins = 0;
@@ -1041,7 +1187,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         }
                         spf_t = -1;
                         const f32x4 f = du_f(v);
-                        if (tid < 80) {                                 // scatter into the [entry][4] layout, every agent twice (entries i and i + N)
+                        if (tid < 40 * SPM) {                           // scatter into the [entry][4] layout, every agent twice (entries i and i + N)
 #pragma unroll
                             for (int e4 = 0; e4 < 4; ++e4) {
                                 const int i = 4 * r_ + e4;
@@ -1057,32 +1203,36 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     DTL(40 * t + 21);
                     {
                         float q_ = 0.f, w_ = 0.f;
-                        du_x_wave<PD>(pb, xp, (DB_XA >> 2) + (wave & 1) * 128, lane, wave >> 1, q_, w_);
+                        // (two own samples: wave = (sample, half of the partner range); one: the four waves take a quarter each)
+                        if (SPM == 2) du_x_wave<PD>(pb, xp, (DB_XA >> 2) + (wave & 1) * 128, lane, wave >> 1, q_, w_);
+                        else du_x_wave<PD, true>(pb, xp, DB_XA >> 2, lane, wave, q_, w_);
                         q_ = sum64(q_); w_ = sum64(w_);
                         if (lane == 0) { lds[DB_XP + 2 * wave] = q_; lds[DB_XP + 2 * wave + 1] = w_; }
                     }
                     __syncthreads();
                     DTL(40 * t + 22);
-                    if (wave == 0 && lane < 2) {                        // sample j = lane: the two halves in a fixed order
-                        const float q_ = lds[DB_XP + 2 * lane] + lds[DB_XP + 2 * (lane + 2)], w_ = lds[DB_XP + 2 * lane + 1] + lds[DB_XP + 2 * (lane + 2) + 1];
+                    if (wave == 0 && lane < SPM) {                      // sample j = lane: the parts in a fixed order
+                        float q_, w_;
+                        if (SPM == 2) { q_ = lds[DB_XP + 2 * lane] + lds[DB_XP + 2 * (lane + 2)]; w_ = lds[DB_XP + 2 * lane + 1] + lds[DB_XP + 2 * (lane + 2) + 1]; }
+                        else { q_ = (lds[DB_XP] + lds[DB_XP + 2]) + (lds[DB_XP + 4] + lds[DB_XP + 6]); w_ = (lds[DB_XP + 1] + lds[DB_XP + 3]) + (lds[DB_XP + 5] + lds[DB_XP + 7]); }
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 pay = {__float_as_uint(q_), __float_as_uint(w_)};
-                        const int off = xQ + ((((e % 3) * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;       // (three slots: see the reset in P3)
+                        const int off = xQ + ((((e % 3) * NT + t) * G + member) * 4 + 2 * lane) * 4;          // (three slots: see the reset in P3)
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 16);      // (the slot is reset below, behind the V gather)
                     }
                     DTL(40 * t + 23);
                 }
                 // ================= P3: a = w + hN K1[:,H_c]^T v ; y = tanh(o) . a =================
-                const int fo = ((par * NT + t) * DU_KBM + 4 * member + wave) * 1024;
+                const int fo = ((par * NT + t) * DU_KBM + MTM * member + ft) * 1024;
                 DTL(40 * t + 24);
-                du_gather<DU_KBM>(g, wave, lane, xV + ((par * NT + t) * DU_KBM) * 1024, DB_VF >> 2, DUK_V);
+                du_gather<DU_KBM>(g, wave, lane, xV + ((par * NT + t) * DU_KBM) * 1024, DB_VF >> 2, DUK_V, DPW_V, t);
                 __syncthreads();
                 DTL(40 * t + 25);
                 u32x4 thv = {DU_SENT, DU_SENT, DU_SENT, DU_SENT};
                 float4 wvs;
                 auto mid = [&](int kb) {
-                    if (kb == DU_KBM - 3) wvs = L4[(DB_VEC >> 2) + 4 * wave + slot];
+                    if (kb == KBW - 3) wvs = L4[(DB_VEC >> 2) + 4 * ft + slot];
                     if (kb != 1) return;
                     // V(e) is complete, so every owner has read the partial gradients of the previous evaluation (it published S(e) after
                     // them): reset those slots now (behind the second k-block: the stores issue in the MFMAs' shadow).  The tanh(o) load is
@@ -1090,19 +1240,22 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // end of P4 (header, H1).  The cost scalars have THREE slots (e mod 3): the owner integrates the costs of evaluation e-1
                     // behind P2 of evaluation e, i.e. possibly after V(e) is complete, so the slot reset here is the one of evaluation e-2
                     // (its reader finished before it published S(e)); it next takes the scalars of evaluation e+1.
-                    const int gR = xG + ((((par ^ 1) * NT + t) * DU_G + member) * DU_KBD) * 1024;
+                    // (fine form: the tanh(o) request goes FIRST -- its answer is then not queued behind the resets' acknowledgements, which P3's 64
+                    // MFMAs are too short to cover; the wait that H1 needs sits in front of P4's stores instead)
+                    if (KS > 1) thv = du_ld(g, vb, xT + fo);
+                    const int gR = xG + ((((par ^ 1) * NT + t) * G + member) * DU_KBD) * 1024;
 #pragma unroll
                     for (int mi = 0; mi < 3; ++mi) { const int mt = wave + 4 * mi; if (mt < DU_KBD) du_st_sent(g, vb, gR + mt * 1024); }
-                    if (wave == 0 && lane < 2) {
+                    if (wave == 0 && lane < SPM) {
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 sen = {DU_SENT, DU_SENT};
-                        const int offr = xQ + (((((e + 1) % 3) * NT + t) * DU_G + member) * 4 + 2 * lane) * 4;
+                        const int offr = xQ + (((((e + 1) % 3) * NT + t) * G + member) * 4 + 2 * lane) * 4;
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 16);
                     }
-                    thv = du_ld(g, vb, xT + fo);
+                    if (KS == 1) thv = du_ld(g, vb, xT + fo);
                 };
-                const f32x4 acc = du_gemm_lds<DU_KBM, true>(W, (DB_VF >> 2) + lane, mid);
+                f32x4 acc = du_gemm_lds<KBW, true>(W, (DB_VF >> 2) + kh * KBW * 64 + lane, mid);
                 // (the first look at the tanh(o) answer stays BEHIND the product: left to itself the scheduler hoists the sentinel test into
                 // the MFMA stream, two k-blocks behind the request, behind an s_waitcnt vmcnt(0) that also waits for the three resets'
                 // acknowledgements)
@@ -1115,59 +1268,114 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         thv = du_ld(g, vb, xT + fo);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the resets above have landed: see there)
+                if (KS == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the resets above have landed: see there; fine form: in front of P4's stores)
+                if (KS > 1) {               // the two halves of the contraction meet (fixed order: lower + upper k-blocks)
+                    L4[(DBPX >> 2) + wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    __syncthreads();
+                    const float4 o4 = L4[(DBPX >> 2) + (wave ^ MTM) * 64 + lane];
+                    const f32x4 ot = {o4.x, o4.y, o4.z, o4.w};
+                    acc = kh ? ot + acc : acc + ot;
+                }
                 {
                     const f32x4 th = du_f(thv);
                     const float4 a4 = make_float4(wvs.x + hN * acc[0], wvs.y + hN * acc[1], wvs.z + hN * acc[2], wvs.w + hN * acc[3]);
                     float4 y;
                     y.x = th[0] * a4.x; y.y = th[1] * a4.y;
                     y.z = th[2] * a4.z; y.w = th[3] * a4.w;
-                    L4[(DB_YF >> 2) + wave * 64 + lane] = y;
-                    if (REC && ra.act && (!fin || ra.tapeSc)) {        // activation record: a = w + hN K1' v
+                    if (KS == 1 || kh == 0) L4[(DB_YF >> 2) + ft * 64 + lane] = y;
+                    if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 1)) {        // activation record: a = w + hN K1' v
                         const long rw = rowg + 16 * t + (lane & 15);
                         if (rw < ra.n)
                             *reinterpret_cast<float4*>(ra.act + 3 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
-                                                       + 64 * member + 16 * wave + 4 * slot) = a4;
+                                                       + HPM * member + 16 * ft + 4 * slot) = a4;
                     }
                 }
                 DTL(40 * t + 27);
                 // (in front of the barrier: they do not depend on y, and the other waves' epilogues cover them)
                 // the own-state pieces of the NEXT tile's cost pass: requested here, in front of P4 and its stores (a load issued behind
                 // a store is not answered before the store is: vmcnt retires in order), consumed at the next tile's entry
-                if (wave < 2 && !fin) {
+                if (wave < SPM && !fin) {
                     const int tn = (t + 1 < NT) ? t + 1 : 0, pn = (t + 1 < NT) ? par : (par ^ 1);
                     const int en = (t + 1 < NT) ? e : e + 1;
                     if (en < E && ((en - 1) % nsub) < nstage) {
-                        const int p = tid < 80 ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, mt = r_ >> 2, sl = r_ & 3;
-                        spf = du_ld(g, xS + ((pn * NT + tn) * DU_KBD + mt) * 1024 + (sl * 16 + 2 * member + j) * 16, 0);
+                        const int p = tid < 40 * SPM ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, pmt = r_ >> 2, sl = r_ & 3;
+                        spf = du_ld(g, xS + ((pn * NT + tn) * DU_KBD + pmt) * 1024 + (sl * 16 + SPM * member + j) * 16, 0);
                         spf_t = tn;
                     }
                 }
-                float4 wf[2][4];
+                const int gP = xG + (((par * NT + t) * G + member) * DU_KBD) * 1024;
+                if (KS > 1) {
+                    // ================= P4 (fine form): partial g = K0[H_c,:]^T y, the wave's dim tiles wave, wave+4 (, wave+8) as ONE stream =================
+                    // 8 MFMAs per dim tile are too few to run tile after tile (750 cycles per tile measured for 256 of issue: every tile paid its
+                    // own operand wait, fence and store): the tiles' chains are interleaved, one fence, then the stores
+                    const bool third = wave + 8 < DU_KBD;
+                    float4 w0[MTM], w1[MTM], w2[MTM];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) wf[0][kb] = L4[(DB_K4 >> 2) + (wave * 4 + kb) * 64 + lane];     // P4's first weights
+                    for (int kb = 0; kb < MTM; ++kb) {
+                        w0[kb] = L4[(DB_K4 >> 2) + (wave * MTM + kb) * 64 + lane];
+                        w1[kb] = L4[(DB_K4 >> 2) + ((wave + 4) * MTM + kb) * 64 + lane];
+                        w2[kb] = L4[(DB_K4 >> 2) + ((third ? wave + 8 : wave) * MTM + kb) * 64 + lane];
+                    }
+                    __syncthreads();
+                    DTL(40 * t + 28);
+                    float4 bf[MTM];
+#pragma unroll
+                    for (int kb = 0; kb < MTM; ++kb) bf[kb] = L4[(DB_YF >> 2) + kb * 64 + lane];
+                    f32x4 a00, a01, a10, a11;
+                    mfma_v0(a00, w0[0].x, bf[0].x); mfma_v0(a10, w1[0].x, bf[0].x);
+                    mfma_v0(a01, w0[0].y, bf[0].y); mfma_v0(a11, w1[0].y, bf[0].y);
+                    mfma_v(a00, w0[0].z, bf[0].z); mfma_v(a10, w1[0].z, bf[0].z);
+                    mfma_v(a01, w0[0].w, bf[0].w); mfma_v(a11, w1[0].w, bf[0].w);
+#pragma unroll
+                    for (int kb = 1; kb < MTM; ++kb) {
+                        mfma_v(a00, w0[kb].x, bf[kb].x); mfma_v(a10, w1[kb].x, bf[kb].x);
+                        mfma_v(a01, w0[kb].y, bf[kb].y); mfma_v(a11, w1[kb].y, bf[kb].y);
+                        mfma_v(a00, w0[kb].z, bf[kb].z); mfma_v(a10, w1[kb].z, bf[kb].z);
+                        mfma_v(a01, w0[kb].w, bf[kb].w); mfma_v(a11, w1[kb].w, bf[kb].w);
+                    }
+                    // (the fence directly behind the stream: accumulators that are live across a branch get copied by the compiler, and a copy
+                    // two states behind an MFMA reads what the matrix pipe is still writing -- tools/mfma_hazard_check.py)
+                    DU_FENCE4(a00, a01, a10, a11);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (H1: the resets issued in P3 have landed before a payload of this evaluation is stored)
+                    du_st(g, vb, gP + wave * 1024, a00 + a01);
+                    du_st(g, vb, gP + (wave + 4) * 1024, a10 + a11);
+                    if (third) {
+                        f32x4 a20, a21;
+                        mfma_v0(a20, w2[0].x, bf[0].x); mfma_v0(a21, w2[0].y, bf[0].y);
+                        mfma_v(a20, w2[0].z, bf[0].z); mfma_v(a21, w2[0].w, bf[0].w);
+#pragma unroll
+                        for (int kb = 1; kb < MTM; ++kb) {
+                            mfma_v(a20, w2[kb].x, bf[kb].x); mfma_v(a21, w2[kb].y, bf[kb].y);
+                            mfma_v(a20, w2[kb].z, bf[kb].z); mfma_v(a21, w2[kb].w, bf[kb].w);
+                        }
+                        DU_FENCE2(a20, a21);
+                        du_st(g, vb, gP + (wave + 8) * 1024, a20 + a21);
+                    }
+                } else {
+                float4 wf[2][MTM];
+#pragma unroll
+                for (int kb = 0; kb < MTM; ++kb) wf[0][kb] = L4[(DB_K4 >> 2) + (wave * MTM + kb) * 64 + lane];     // P4's first weights
                 __syncthreads();
                 DTL(40 * t + 28);
                 // ================= P4: partial g = K0[H_c,:]^T y for the dim tiles wave, wave+4, wave+8 =================
-                const int gP = xG + (((par * NT + t) * DU_G + member) * DU_KBD) * 1024;
                 {
-                    float4 bf[4];
+                    float4 bf[MTM];
 #pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) bf[kb] = L4[(DB_YF >> 2) + kb * 64 + lane];
+                    for (int kb = 0; kb < MTM; ++kb) bf[kb] = L4[(DB_YF >> 2) + kb * 64 + lane];
 #pragma unroll
                     for (int mi = 0; mi < 3; ++mi) {
                         const int mt = wave + 4 * mi;
                         if (mt < DU_KBD) {
                             if (mi < 2 && mt + 4 < DU_KBD) {
 #pragma unroll
-                                for (int kb = 0; kb < 4; ++kb) wf[(mi + 1) & 1][kb] = L4[(DB_K4 >> 2) + ((mt + 4) * 4 + kb) * 64 + lane];
+                                for (int kb = 0; kb < MTM; ++kb) wf[(mi + 1) & 1][kb] = L4[(DB_K4 >> 2) + ((mt + 4) * MTM + kb) * 64 + lane];
                             }
-                            const float4 (&w4)[4] = wf[mi & 1];
+                            const float4 (&w4)[MTM] = wf[mi & 1];
                             f32x4 a0, a1;
                             mfma_v0(a0, w4[0].x, bf[0].x); mfma_v0(a1, w4[0].y, bf[0].y);
                             mfma_v(a0, w4[0].z, bf[0].z); mfma_v(a1, w4[0].w, bf[0].w);
 #pragma unroll
-                            for (int kb = 1; kb < 4; ++kb) {
+                            for (int kb = 1; kb < MTM; ++kb) {
                                 mfma_v(a0, w4[kb].x, bf[kb].x); mfma_v(a1, w4[kb].y, bf[kb].y);
                                 mfma_v(a0, w4[kb].z, bf[kb].z); mfma_v(a1, w4[kb].w, bf[kb].w);
                             }
@@ -1176,6 +1384,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         }
                     }
                 }
+                }
+                du_anchor(g, t, lane);
                 if (dp.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 DTL(40 * t + 29);
             }
@@ -1192,19 +1402,22 @@ static int du_env_int(const char* name, int dflt) { return nocf_env_int(name, df
 
 long duo_rows_per_launch(void) { return 32L * 16 * DU_NTMAX; }
 
-static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false, bool dw = false) {
+// G: members per group of the forward (8: the form of rounds 3-4; 16: the fine form, DuoCfg); the adjoint always runs with 8
+static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false, bool dw = false, int G = DU_G) {
     if (nTh != 2 || m != 64 * DU_G || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
+    if ((G != DU_G && G != DU_GMAX) || (G != DU_G && (bwd || dw))) return NOCF_E_SHAPE;
     DuoPlan dp;
     memset(&dp, 0, sizeof(dp));
-    dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents;
+    dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents; dp.G = G;
     const long ntiles = (n + 15) / 16;
-    dp.ngroups = (int)std::min<long>(dw ? 16 : 32, ntiles);     // (dw: 32 workgroups per group, 16 groups fill the chip)
+    dp.ngroups = (int)std::min<long>((dw ? 16 : 32) * DU_G / G, ntiles);     // (512 workgroups fill the chip: 32 groups of 16, 16 groups of 32 (dw, fine form))
     dp.dw = dw ? 1 : 0;
     dp.NT = (int)((ntiles + dp.ngroups - 1) / dp.ngroups);
     if (dp.NT > DU_NTMAX) return NOCF_E_SHAPE;
     dp.hN = 1.0f;
     if (bwd && r > 10) return NOCF_E_SHAPE;                                        // (the adjoint keeps 10 rows of A in LDS)
-    const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE : DA_T + 2 * dp.NT * DS_STRIDE, ldsB = DB_END;
+    const int fine = G != DU_G ? 1024 : 0;                                         // (the waves' partial sums: see the kernel)
+    const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE : DA_T + fine + 4 * DPW_WORDS + (16 / G) * dp.NT * DS_STRIDE, ldsB = DB_END + (bwd ? 0 : 4 * DPW_WORDS);
     dp.ldsFloats = std::max(std::max(ldsA, ldsB), dw ? DC_END : 0);
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
     long o = 0;                                                                    // floats
@@ -1223,7 +1436,7 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
     dp.oCW = o; o += DU_DP;
     o = (o + 63) / 64 * 64;
     dp.oX = o;
-    dp.xStride = duo_x_layout(dp.NT, nullptr, bwd);
+    dp.xStride = duo_x_layout(dp.NT, nullptr, bwd, G);
     *out = dp;
     return 0;
 }
@@ -1236,25 +1449,42 @@ int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size
     if (rc) return rc;
     size_t b = duo_ws_bytes_of(dp);
     if (make_duo_plan(d, m, nTh, r, n_agents, std::min<long>(n, duo_rows_per_launch()), &db, true) == 0) b = std::max(b, duo_ws_bytes_of(db));   // (the adjoint's exchange area is larger)
+    if (make_duo_plan(d, m, nTh, r, n_agents, std::min<long>(n, duo_rows_per_launch()), &db, false, false, DU_GMAX) == 0) b = std::max(b, duo_ws_bytes_of(db));   // (the fine form's partial-gradient area too)
     if (bytes) *bytes = b;
     return 0;
 }
 
-template <int PD, bool REC, bool ZF>
-static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF>); }
+template <int PD, bool REC, bool ZF, int GM>
+static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF, GM>); }
+template <int GM>
+static const void* duo_pick(bool c2, bool rec, bool zf) {
+    return c2 ? (rec ? duo_fn<2, true, false, GM>() : (zf ? duo_fn<2, false, true, GM>() : duo_fn<2, false, false, GM>()))
+              : (rec ? duo_fn<3, true, false, GM>() : (zf ? duo_fn<3, false, true, GM>() : duo_fn<3, false, false, GM>()));
+}
+
+// Which form for a launch of n rows?  NOCF_DUO_G = 8 / 16 forces one; otherwise the fine form where the batch has at most 16 tiles, i.e.
+// where it has ONE tile per group (measured on the MI355X, profiles/r5/05_proxy_table.txt: 128 rows 2.35 ms against 2.95, 256 rows 2.77 against
+// 2.95; with several tiles per group the two roles' tiles overlap on every SIMD, the MFMA and vector pipes exclude each other, and twice the
+// workgroups per tile mean twice the epilogue / gather instructions per tile: 512 rows 3.9 against 3.3, 1024 rows 7.9 against 5.2)
+static int duo_pick_G(long n) {
+    const int forced = du_env_int("NOCF_DUO_G", 0);
+    if (forced == DU_G || forced == DU_GMAX) return forced;
+    return (n + 15) / 16 <= 16 ? DU_GMAX : DU_G;
+}
 
 int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, float* ws, size_t ws_bytes, hipStream_t st,
                const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
     if (pb.kind == NOCF_PROB_QUADCOPTER || (ra_in.zFull && ra_in.sAll)) return 1;
-    const long chunk = duo_rows_per_launch();
+    const int GM = duo_pick_G(ra_in.n);
+    const long chunk = duo_rows_per_launch() * DU_G / GM;         // (the fine form has half as many groups per launch)
     DuoPlan dp0;
-    if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(ra_in.n, chunk), &dp0) != 0) return 1;
+    if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(ra_in.n, chunk), &dp0, false, false, GM) != 0) return 1;
     if (ws_bytes < duo_ws_bytes_of(dp0)) return 1;
     const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
     const bool rec = ra_in.sAll != nullptr;
     const bool zf = ra_in.zFull != nullptr;
-    const void* fk = c2 ? (rec ? duo_fn<2, true, false>() : (zf ? duo_fn<2, false, true>() : duo_fn<2, false, false>()))
-                        : (rec ? duo_fn<3, true, false>() : (zf ? duo_fn<3, false, true>() : duo_fn<3, false, false>()));
+    const void* fk = GM == DU_G ? duo_pick<DU_G>(c2, rec, zf) : duo_pick<DU_GMAX>(c2, rec, zf);
+    const int wpg = 2 * GM;
     // residency: all 16 x ngroups workgroups spin on each other, so every one of them must be resident at once: two per CU
     // (256 registers per lane, <= 80 KB LDS).  The grid is checked against what the runtime says fits; the stream must be
     // otherwise idle (a concurrent kernel on another stream can take the CUs: the bounded polls then time out and the host raises).
@@ -1264,7 +1494,7 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
     hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024));
     if (e) return (int)e;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fk, 256, ldsBytes0) != hipSuccess) return 1;
-    const int grid0 = 128 * ((dp0.ngroups + 7) / 8);
+    const int grid0 = 8 * wpg * ((dp0.ngroups + 7) / 8);
     if ((long)perCU * cus < grid0) {
         if (debug) fprintf(stderr, "[nocf] duo kernel: grid %d does not fit (%d workgroups per CU x %d CUs)\n", grid0, perCU, cus);
         return 1;
@@ -1273,12 +1503,12 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
     for (long r0 = 0; r0 < ra_in.n; r0 += chunk) {
         const long cn = std::min<long>(chunk, ra_in.n - r0);
         DuoPlan dp;
-        int rc = make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cn, &dp);
+        int rc = make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, cn, &dp, false, false, GM);
         if (rc) return rc;
         dp.cb = phi->cb;
         dp.fast = du_env_int("NOCF_DUO_FAST", 1);
         dp.mapmode = du_env_int("NOCF_DUO_MAP", 3);                 // bit 0: A / B of a member adjacent in the static map; bit 1: CU census (see the kernel)
-        dp.dbg = du_env_int("NOCF_DUO_DBG", 0);
+        dp.dbg = (du_env_int("NOCF_DUO_DBG", 0) & 0xff) | ((du_env_int("NOCF_DUO_UDELAY", dp.NT == 1 ? 0 : 6) & 15) << 8);   // (measured: n = 1024 5.21 -> 5.15 ms with 6, nothing with one tile)
         dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
         // (every chunk: the plan record changes with the chunk's rows; the same launch clears the error words / tables and fills the
         // exchange area with the sentinel)
@@ -1292,18 +1522,18 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
         DuoRun rr{r0, ra_in.n};
         const DuoPlan* dpp = reinterpret_cast<const DuoPlan*>(ws + dp.oPlan);
         const size_t ldsBytes = (size_t)dp.ldsFloats * 4;
-        if (debug) fprintf(stderr, "[nocf] duo kernel: rows %ld..%ld, %d groups x 16 workgroups, %d tile(s) of 16 samples, LDS %zu B/workgroup, %d workgroups/CU fit\n",
-                           r0, r0 + cn, dp.ngroups, dp.NT, ldsBytes, perCU);
+        if (debug) fprintf(stderr, "[nocf] duo kernel: rows %ld..%ld, %d groups x %d workgroups, %d tile(s) of 16 samples, LDS %zu B/workgroup, %d workgroups/CU fit\n",
+                           r0, r0 + cn, dp.ngroups, wpg, dp.NT, ldsBytes, perCU);
         void* args[] = {(void*)&dpp, (void*)&pb, (void*)&ws, (void*)&ra, (void*)&rr};
         if (ev0 && r0 == 0) (void)hipEventRecord(ev0, st);
-        e = hipLaunchKernel(fk, dim3(128 * ((dp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st);
+        e = hipLaunchKernel(fk, dim3(8 * wpg * ((dp.ngroups + 7) / 8)), dim3(256), args, ldsBytes, st);
         if (e) return (int)e;
         if (ev1 && r0 + chunk >= ra_in.n) (void)hipEventRecord(ev1, st);
         if (debug >= 2) {
             unsigned w[2] = {0, 0};
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(w, ws + dp.oErr, 8, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[nocf] duo kernel: error word 0x%x, %u of %d workgroups paired by the CU census\n", w[0], w[1], 16 * dp.ngroups);
+            fprintf(stderr, "[nocf] duo kernel: error word 0x%x, %u of %d workgroups paired by the CU census\n", w[0], w[1], wpg * dp.ngroups);
         }
     }
     *errp = reinterpret_cast<const unsigned*>(ws) + dp0.oErr;

@@ -40,7 +40,8 @@ def main():
     tall = buf[:64 * 128].view(8, 2, 4, 128).cpu()          # [member][role][wave][point]
     tl = tall[0]
     t0 = int(tl[tl > 0].min())
-    nt_tiles = max(1, min(4, (((n + 15) // 16) + 31) // 32))
+    ngmax = 16 if os.environ.get("NOCF_DUO_G", "16") == "16" else 32           # groups per launch: 16 of 32 workgroups (fine form) or 32 of 16
+    nt_tiles = max(1, min(4, (((n + 15) // 16) + ngmax - 1) // ngmax))
     rows = []
     for t in range(nt_tiles):
         for i, name in A_PT.items():
