@@ -149,7 +149,10 @@ def cpu_baseline(meta, sd, xtarget, x, nt, budget_s=60.0):
             "extrapolated_traj_per_s": traj[head], "full_rollout_s": full_s, "full_rollout_traj_per_s": (n / full_s) if full_s else None,
             "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
             "one_thread": traj[1], "all_cores": traj[ncpu], "all_cores_count": ncpu, "best_probe": traj[best], "best_probe_threads": best,
-            "sample": f"n={n} rows, the first steps of the {nt}-step RK4 rollout at the same h, scaled to {nt} steps; {legtxt}; "
+            "sample": f"PROTOCOL: not SURVEY 8(d)'s >= 20 full calls (a full rollout takes seconds on this host) but, per leg, 3 warm-up steps and the "
+                      f"median of 3 calls of <= 8 RK4 steps, scaled to {nt} steps -- validated in this run by ONE full {nt}-step rollout at the headline "
+                      f"thread count (full_rollout_s; beyond 10 % disagreement the measured rollout becomes `value`).  n={n} rows, the first steps of "
+                      f"the {nt}-step RK4 rollout at the same h; {legtxt}; "
                       f"thread probe (1 step, traj/s-equivalent): {table}" + ("; " + "; ".join(notes) if notes else "")
                       + f"; eager PyTorch {torch.__version__}",
             "seconds_per_step": legs[head][0]}
@@ -208,7 +211,7 @@ def bench_shock(args, dev):
     print(json.dumps(out), flush=True)
 
 
-def quick_measure(name, dev, steps=10, warmup=3):
+def quick_measure(name, dev, steps=10, warmup=3, n_rows=0):
     """one of the other BASELINE.json configurations at its full size, a few calls (the headline stays swarm50): what the driver's line
     carries in config.other_workloads"""
     L = _lib.lib()
@@ -234,7 +237,7 @@ def quick_measure(name, dev, steps=10, warmup=3):
                 "traj_per_s": len(times) * n / el, "ms_per_sweep": 1e3 * el, "kernel": L.nocf_last_rollout_kernel().decode()}
     meta, sd, xtarget, xInit = load_workload(name)
     net, prob = build_objects(meta, sd, xtarget, dev)
-    n, nt = meta["n_full"], meta["nt"]
+    n, nt = n_rows or meta["n_full"], meta["nt"]
     x = make_states(meta, xInit, n, seed=200).to(dev)
     with torch.no_grad():
         for _ in range(warmup):
@@ -307,7 +310,7 @@ def train_measure(name, dev, reps=10):
             "trained_traj_per_s": n / el, "forward_kernel": fk, "forward_kernel_ms": fwd_ms / kreps,
             "adjoint_kernel": bk, "adjoint_kernel_ms": bwd_ms / kreps, "flops_per_iteration": fl,
             "frac": fl / el / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "frac_of": "3 x SURVEY 8(d) forward FLOPs per iteration over the WHOLE iteration's wall time, of the fp32 MFMA peak", "Jc": float(Jc)}
+            "frac_of": "3 x SURVEY 8(d) forward FLOPs per iteration over the WHOLE iteration's wall time, of the fp32 MFMA peak", "Jc": float(Jc.detach())}
 
 
 def self_launch(args):
@@ -449,6 +452,15 @@ def main():
                     others.append(quick_measure(name, dev))
                 except Exception as ex:                          # the headline line must survive a failure here
                     others.append({"workload": name, "error": repr(ex)[:200]})
+            # the per-rank batches of the strong-scaling partition of the headline config (n_train = 1024 over 2 / 4 / 8 GPUs) and of
+            # config 5 at 8 GPUs, on this one GPU: what a rank's rollout costs when the node is not there to measure it
+            for name, rows in (("swarm50", 512), ("swarm50", 256), ("swarm50", 128), ("singlequad", 512)):
+                try:
+                    r = quick_measure(name, dev, steps=20, n_rows=rows)
+                    r["proxy_for"] = f"one rank's batch of {name} at {1024 // rows if name == 'swarm50' else 4096 // rows} GPUs (strong scaling)"
+                    others.append(r)
+                except Exception as ex:
+                    others.append({"workload": f"{name} n={rows}", "error": repr(ex)[:200]})
             for name in ("swarm50", "singlequad"):               # training: the reference's main use (trainOC.py:160-176)
                 try:
                     others.append(train_measure(name, dev))

@@ -110,6 +110,10 @@ int nocf_last_rollout_status_async(uint32_t* host_word, void* stream);
 /* The library reads its NOCF_* environment knobs once (first use) and caches them; this drops the cache so that the next call reads
  * the environment again (tests that switch kernels between calls; the Python layer calls it when NOCF_ENV_WATCH=1). */
 void nocf_debug_reload_env(void);
+/* Override one NOCF_* knob for THIS process's library instance (clear != 0: drop the override again).  Unlike the environment it is not
+ * inherited by child processes (compiler children, self-launched ranks) and survives nocf_debug_reload_env: the in-process fallback of a
+ * process that shares its GPU (neuraloc_amd/_lib.py: duo_guard) uses it to switch the weight-stationary kernels off. */
+int nocf_set_knob(const char* name, int32_t value, int32_t clear);
 
 /* bytes of scratch `workspace` a call with these shapes needs (packed weight images) */
 size_t nocf_workspace_bytes(int32_t d, int32_t m, int32_t nTh);
@@ -150,6 +154,29 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob,
                      float* z_out, float* persample, float* cost_sums,
                      float* zFull, float* ctrlFull,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Several rollouts that differ only in their start time and step count, in ONE launch (round 5): the second segments of a shock sweep.
+ * The reference's shocked rollout (src/plotter.py:815-824, driven by evalOC.py:113-122) is OCflow on [0, t_s] with int(t_s nt) steps, the
+ * shock added to the end state, and OCflow on [t_s, 1] with 1 + nt - int(t_s nt) steps; a sweep over shock times (BASELINE config 5) repeats
+ * that per t_s.  Here rows [k * rows_per_seg, (k + 1) * rows_per_seg) of x are segment k: integrated over [t0s[k], t1] with nts[k] steps of
+ * h_k = (t1 - t0s[k]) / nts[k], exactly what nocf_rollout_f32(x_k, ..., t0s[k], t1, nts[k], ...) computes for those rows (bit for bit: same
+ * kernel, same per-tile arithmetic), but the launch covers all segments' tiles at once -- 9 x 512 rows fill the chip where 512 rows occupy an
+ * eighth of it.
+ *   nseg <= 16 segments; rows_per_seg a multiple of 16; (nseg - 1) * rows_per_seg < n <= nseg * rows_per_seg (a ragged last segment).
+ *   t0s, nts       HOST arrays of nseg entries (copied into the kernel arguments)
+ *   slot0s         HOST array (nullable = zeros): the first time slot of segment k in zFull / ctrlFull.  With slot0s[k] = int(t_s nt) + 1 the
+ *                  caller's buffer holds, per row, the reference's concatenation cat(traj1, traj2) (src/plotter.py:822): it fills the slots
+ *                  in front of slot0s[k] with the unshocked segment
+ *   zFull          device [max(slot0s + nts) + 1, n, d+4], time-major as in nocf_rollout_f32; segment k writes slots slot0s[k] .. + nts[k] only
+ *   ctrlFull       likewise                      cost_sums   device [nseg, 8]: one row of sums per segment
+ * Returns NOCF_E_SHAPE when the network / problem has no one-CU weight-stationary kernel (singlequad has; nothing is launched then, and
+ * the caller runs the segments one by one).
+ */
+int nocf_rollout_segments_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                              int32_t nseg, int64_t rows_per_seg, const double* t0s, double t1, const int32_t* nts, const int32_t* slot0s,
+                              int32_t stepper, const float* alph, float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * The last lines of OCflow (src/OCflow.py:80-90): out[0..6] = cost_sums[0..6] / cost_sums[7] (the batch means

@@ -38,6 +38,9 @@ def _launch64(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
         raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
     if len(alph) < 6:
         raise ValueError("alph needs 6 entries")
+    # (only the mean path is differentiable -- OCflow routes it to train._OCflowTrain64 before it gets here; noMean / intermediates under
+    # autograd raise like the single-precision launch does, instead of returning detached tensors)
+    Phi._guard_no_autograd(x, "OCflow")
     phi_st, keep1, ws = Phi._c_struct64()
     prob_st, keep2 = prob._c_struct64(x.device)
     dev = x.device
@@ -101,6 +104,58 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
     _lib.track_rollout_status(L, dev, "OCflow")
     if _lib.duo_guard(L, "OCflow"):
         return _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates)
+    return persample, sums, zFull, ctrlFull
+
+
+MAX_SEGMENTS = 16
+
+
+def _launch_segments(x, Phi, prob, t0s, t1, nts, rows_per_seg, stepper, alph, slot0s=None, zFull=None, ctrlFull=None):
+    """Several rollouts that differ only in start time and step count in ONE launch (nocf_rollout_segments_f32): rows
+    [k * rows_per_seg, (k + 1) * rows_per_seg) of x are integrated over [t0s[k], t1] with nts[k] steps, trajectories and controls kept:
+    segment k writes the time slots slot0s[k] .. slot0s[k] + nts[k] of zFull / ctrlFull (time-major [slots, n, .]; allocated here when not
+    given).  Returns (persample [n,7], sums [nseg,8], zFull_tm, ctrlFull_tm), or None when this network / problem has no kernel that takes
+    segments (the caller then launches them one by one)."""
+    x = _lib.require_device_f32(x, "x")
+    n, d = x.shape
+    nseg = len(t0s)
+    if not (1 <= nseg <= MAX_SEGMENTS) or len(nts) != nseg or rows_per_seg % 16 or not ((nseg - 1) * rows_per_seg < n <= nseg * rows_per_seg):
+        return None
+    if stepper not in _STEPPERS:
+        raise ValueError(f"stepper must be 'rk4' or 'rk1', got {stepper!r}")
+    if min(int(v) for v in nts) < 1:
+        raise ValueError("nt must be >= 1")
+    slot0s = [0] * nseg if slot0s is None else [int(v) for v in slot0s]
+    Phi._guard_no_autograd(x, "shock sweep")
+    _lib.check_errors()
+    phi_st, keep1, ws = Phi._c_struct(n)
+    prob_st, keep2 = prob._c_struct(x.device)
+    dev = x.device
+    L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents)
+    if not hasattr(L, "nocf_rollout_segments_f32"):
+        return None
+    slots = max(s0 + int(v) for s0, v in zip(slot0s, nts)) + 1
+    persample = torch.empty(n, 7, dtype=torch.float32, device=dev)
+    sums = torch.empty(nseg, 8, dtype=torch.float32, device=dev)
+    cdim = _lib.lib().nocf_ctrl_dim(C.byref(prob_st), d)
+    if zFull is None:
+        zFull = torch.empty(slots, n, d + 4, dtype=torch.float32, device=dev)
+        ctrlFull = torch.empty(slots, n, cdim, dtype=torch.float32, device=dev)
+    if (tuple(zFull.shape) != (zFull.shape[0], n, d + 4) or tuple(ctrlFull.shape) != (zFull.shape[0], n, cdim) or zFull.shape[0] < slots
+            or not zFull.is_contiguous() or not ctrlFull.is_contiguous()):
+        raise ValueError("zFull / ctrlFull must be contiguous [slots, n, d+4] / [slots, n, a] with enough slots")
+    alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
+    t0_c = (C.c_double * nseg)(*[float(v) for v in t0s])
+    nt_c = (C.c_int32 * nseg)(*[int(v) for v in nts])
+    s0_c = (C.c_int32 * nseg)(*slot0s)
+    with torch.cuda.device(dev):
+        rc = L.nocf_rollout_segments_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n, nseg, int(rows_per_seg), t0_c, float(t1), nt_c, s0_c,
+                                         _STEPPERS[stepper], alph_c, None, _lib.ptr(persample), _lib.ptr(sums),
+                                         _lib.ptr(zFull), _lib.ptr(ctrlFull), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    if rc == -2:                                           # NOCF_E_SHAPE: no kernel with segments for this shape
+        return None
+    _lib.check(rc, "nocf_rollout_segments_f32")
+    _lib.track_rollout_status(L, dev, "shock sweep")
     return persample, sums, zFull, ctrlFull
 
 

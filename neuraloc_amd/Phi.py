@@ -10,6 +10,7 @@ import copy
 import ctypes as C
 
 import torch
+from torch.autograd.function import once_differentiable
 import torch.nn as nn
 
 from . import _lib
@@ -241,6 +242,7 @@ class _PhiValueFn(torch.autograd.Function):
         return net._value_f32(xd)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         (x,) = ctx.saved_tensors
         net = ctx.net
@@ -291,6 +293,7 @@ class _PhiGradFn(torch.autograd.Function):
         return net._grad_f32(xd)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gbar):
         (x,) = ctx.saved_tensors
         net = ctx.net

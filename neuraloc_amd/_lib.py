@@ -215,6 +215,11 @@ def lib_for(d, m, nTh, r, n_agents):
 
 def _bind(L):
     L.nocf_version.restype = C.c_int
+    if hasattr(L, "nocf_set_knob"):
+        L.nocf_set_knob.restype = C.c_int
+        L.nocf_set_knob.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+        if _duo_fallback["on"]:
+            L.nocf_set_knob(b"NOCF_DUO", 0, 0)
     L.nocf_last_rollout_kernel.restype = C.c_char_p
     L.nocf_workspace_bytes.restype = C.c_size_t
     L.nocf_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
@@ -227,6 +232,12 @@ def _bind(L):
                                    C.c_double, C.c_double, C.c_int32, C.c_int32, fp,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]
+    if hasattr(L, "nocf_rollout_segments_f32"):
+        L.nocf_rollout_segments_f32.restype = C.c_int
+        L.nocf_rollout_segments_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_void_p, C.c_int64,
+                                                C.c_int32, C.c_int64, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, fp,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.c_void_p]
     L.nocf_small_grad_floats.restype = C.c_int64
     L.nocf_small_grad_floats.argtypes = [C.c_int32, C.c_int32]
     L.nocf_rollout_bwd_small_f32.restype = C.c_int
@@ -393,10 +404,19 @@ _duo_probation = {"left": int(os.environ.get("NOCF_DUO_PROBATION", "3"))}
 
 
 def duo_guard(L, what):
-    """call right behind track_rollout_status; True: the launch timed out during probation, the split-role kernels are now off, repeat the call"""
+    """call right behind track_rollout_status; True: the launch timed out during probation, the split-role kernels are now off, repeat the call.
+    Only the launch that was JUST tracked can trigger the fallback: older pending rollouts are drained first and a failure among them raises
+    as it would have anyway (their NaN results are already out).  The switch is a library-level override (nocf_set_knob), not an environment
+    variable: children of this process (compiler, self-launched ranks) do not inherit it; every rank prints its own message."""
     if _duo_probation["left"] <= 0 or not L.nocf_last_rollout_kernel().decode().startswith("rollout_duo"):
         return False
     _duo_probation["left"] -= 1
+    mine = _pending.pop() if _pending else None             # the entry track_rollout_status just added
+    try:
+        check_errors(sync=True)                             # earlier launches: a failure here is theirs and is raised as such
+    finally:
+        if mine is not None:
+            _pending.append(mine)
     try:
         check_errors(sync=True)
         return False
@@ -404,14 +424,18 @@ def duo_guard(L, what):
         if os.environ.get("NOCF_DUO_FALLBACK", "1") in ("0", ""):
             raise
         import sys
-        print(f"[neuraloc_amd] {what}: {str(ex).split(';')[0]}; the GPU seems to be shared -- switching this process to the per-tile kernels "
-              "(NOCF_DUO=0) and repeating the call", file=sys.stderr, flush=True)
-        os.environ["NOCF_DUO"] = "0"
+        rank = os.environ.get("RANK")
+        print(f"[neuraloc_amd]{'' if rank is None else ' rank ' + rank}: {what}: {str(ex).split(';')[0]}; the GPU seems to be shared -- switching "
+              "this process to the per-tile kernels (NOCF_DUO=0 as a library override) and repeating the call", file=sys.stderr, flush=True)
         for lib_ in [_lib] + list(_jit_libs.values()):
-            if lib_ is not None:
-                lib_.nocf_debug_reload_env()
+            if lib_ is not None and hasattr(lib_, "nocf_set_knob"):
+                lib_.nocf_set_knob(b"NOCF_DUO", 0, 0)
+        _duo_fallback["on"] = True
         _duo_probation["left"] = 0
         return True
+
+
+_duo_fallback = {"on": False}
 
 
 def check(rc, what):

@@ -136,6 +136,12 @@ __device__ __forceinline__ bool want_W(const DevProb& pb) {
     return (pb.kind == NOCF_PROB_QUADCOPTER) ? (pb.alphW > 0.0) : (pb.alphW != 0.0);
 }
 
+// Several time segments in ONE launch (include/nocf.h, nocf_rollout_segments_f32; BASELINE config 5's shock sweep: the second segments of all
+// shock times at once): rows [k * rows, (k + 1) * rows) of the batch are integrated over [t0[k], RollArgs::t1] with nt[k] steps.  n = 0: one
+// segment, RollArgs::t0 / nt / h.  Passed by value (272 bytes of kernel arguments; only the one-CU kernel reads it).
+#define NOCF_MAX_SEG 16
+struct SegTab { int n, rows; double t0[NOCF_MAX_SEG]; int nt[NOCF_MAX_SEG]; int slot0[NOCF_MAX_SEG]; };      // slot0: first time slot of the segment in zFull / ctrlFull
+
 struct RollArgs {
     const float* x; long n;
     double t0, t1, h; int nt, stepper;
@@ -152,4 +158,5 @@ struct RollArgs {
     // of the terminal evaluation ([n][m]) and four scalars per evaluation and sample ([actRows][4]: dPhi/dt - H, the x-only cost terms
     // q and w of that state, 0; terminal block: Phi - alph0 G, 0, 0, 0).  Null: no tape.
     float* tapeU1; float* tapeSc;
+    SegTab seg;
 };

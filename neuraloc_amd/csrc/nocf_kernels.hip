@@ -1535,8 +1535,11 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ a, const float* _
 #include <string>
 static std::mutex g_env_mu;
 static std::map<std::string, int> g_env_cache;
+static std::map<std::string, int> g_env_override;          // nocf_set_knob: in-process overrides, not touched by a reload
 int nocf_env_int(const char* name, int dflt) {
     std::lock_guard<std::mutex> lk(g_env_mu);
+    auto ov = g_env_override.find(name);
+    if (ov != g_env_override.end()) return ov->second;
     auto it = g_env_cache.find(name);
     if (it != g_env_cache.end()) return it->second == INT32_MIN ? dflt : it->second;
     const char* v = getenv(name);
@@ -1701,6 +1704,13 @@ const char* nocf_last_rollout_kernel(void) { return g_last_kernel; }
 void nocf_debug_reload_env(void) {
     std::lock_guard<std::mutex> lk(g_env_mu);
     g_env_cache.clear();
+}
+
+int nocf_set_knob(const char* name, int32_t value, int32_t clear) {
+    if (!name || strncmp(name, "NOCF_", 5) != 0) return NOCF_E_NULL;
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    if (clear) g_env_override.erase(name); else g_env_override[name] = value;
+    return 0;
 }
 
 int nocf_last_rollout_status_async(uint32_t* host_word, void* stream) {
@@ -1872,7 +1882,8 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
                         double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
                         float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
                         void* workspace, size_t workspace_bytes, void* stream, float* s_all,
-                        float* act = nullptr, int32_t* act_recorded = nullptr, float* tapeU1 = nullptr, float* tapeSc = nullptr) {
+                        float* act = nullptr, int32_t* act_recorded = nullptr, float* tapeU1 = nullptr, float* tapeSc = nullptr,
+                        const SegTab* seg = nullptr) {
     if (act_recorded) *act_recorded = 0;
     int rc = check_phi(phi);
     if (rc) return rc;
@@ -1898,6 +1909,8 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     ra.cdim = nocf_ctrl_dim(prob, phi->d);
     ra.stamps = g_stamp_buf;
     ra.sAll = s_all;
+    memset(&ra.seg, 0, sizeof(ra.seg));
+    if (seg) ra.seg = *seg;                       // (several time segments in one launch: the one-CU kernel only, NOCF_E_SHAPE otherwise)
     ra.act = nullptr; ra.actRows = 0;             // (only the split-role kernel records activations: set below)
     ra.tapeU1 = nullptr; ra.tapeSc = nullptr;
     hipError_t e;
@@ -1906,7 +1919,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     g_last_errp = nullptr;
     // small networks: one wave per sample, everything in registers (nocf_lane.inc); needs no packed images
     const bool lane_ok = env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&
-                         pb.kind != NOCF_PROB_QUADCOPTER && pb.nAgents <= 16 && !g_stamp_buf;
+                         pb.kind != NOCF_PROB_QUADCOPTER && pb.nAgents <= 16 && !g_stamp_buf && !seg;
     if (lane_ok) {
         LaneArgs la;
         la.P = DevPhi{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
@@ -1937,7 +1950,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
 #ifndef NOCF_JIT_ONLY
     // split-role weight-stationary kernel (nocf_duo.hip): wide two-layer networks (m = 512) on point-agent problems, any batch
     // size (chunks of 2048 rows), evaluation and the recording forward of training
-    if (env_int("NOCF_DUO", 1) != 0) {
+    if (env_int("NOCF_DUO", 1) != 0 && !seg) {
         if (g_prof_on) {
             if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
         }
@@ -2000,13 +2013,22 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         e = hipGetLastError();
         if (e) return (int)e;
         if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
-        if (cost_sums) {
+        if (cost_sums && seg) {                       // one row of 8 sums per segment
+            for (int k = 0; k < seg->n; ++k) {
+                const long r0 = (long)k * seg->rows, rn = std::min<long>(seg->rows, (long)n - r0);
+                if (rn <= 0) break;
+                hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample + r0 * 7, rn, cost_sums + 8 * k, errp);
+            }
+            e = hipGetLastError();
+            if (e) return (int)e;
+        } else if (cost_sums) {
             hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
             e = hipGetLastError();
             if (e) return (int)e;
         }
         return 0;
     }
+    if (seg) return NOCF_E_SHAPE;                     // (segments: no one-CU instantiation for this shape -- the caller launches them one by one)
     {
         const size_t ldsBytes = (size_t)pl.ldsFloats * 4;
         const int grid = (int)((n + pl.T - 1) / pl.T);
@@ -2062,6 +2084,27 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
                      void* workspace, size_t workspace_bytes, void* stream) {
     return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, zFull, ctrlFull,
                         workspace, workspace_bytes, stream, nullptr);
+}
+
+int nocf_rollout_segments_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                              int32_t nseg, int64_t rows_per_seg, const double* t0s, double t1, const int32_t* nts, const int32_t* slot0s,
+                              int32_t stepper, const float* alph, float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    if (!t0s || !nts) return NOCF_E_NULL;
+    if (nseg < 1 || nseg > NOCF_MAX_SEG || rows_per_seg < 16 || (rows_per_seg % 16) != 0 || rows_per_seg > 0x7fffffffL ||
+        n > (int64_t)nseg * rows_per_seg || n <= (int64_t)(nseg - 1) * rows_per_seg) return NOCF_E_SHAPE;
+    SegTab sg;
+    memset(&sg, 0, sizeof(sg));
+    sg.n = nseg; sg.rows = (int)rows_per_seg;
+    int ntmax = 0;
+    for (int k = 0; k < nseg; ++k) {
+        if (nts[k] < 1) return NOCF_E_SHAPE;
+        if (slot0s && slot0s[k] < 0) return NOCF_E_SHAPE;
+        sg.t0[k] = t0s[k]; sg.nt[k] = nts[k]; sg.slot0[k] = slot0s ? slot0s[k] : 0;
+        ntmax = std::max(ntmax, (int)nts[k]);
+    }
+    return rollout_impl(phi, prob, x, n, t0s[0], t1, ntmax, stepper, alph, z_out, persample, cost_sums, zFull, ctrlFull,
+                        workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr, nullptr, &sg);
 }
 
 int nocf_rollout_record_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,

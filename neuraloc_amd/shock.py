@@ -10,6 +10,7 @@ from importlib import import_module
 
 _oc = import_module(__package__ + ".OCflow")           # the module, not the function the package re-exports under the same name
 from .OCflow import costs_from_sums
+from . import _lib
 
 
 def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, stepper="rk4", group=None, gather=False):
@@ -57,12 +58,108 @@ def shock_rollout(x, Phi, prob, nt, t_s, shock, tspan=(0.0, 1.0), alph=None, ste
     return {"traj": traj, "ctrl": ctrl, "costs1": costs1, "costs2": costs2, "nShock": nShock, "x_shocked": xs}
 
 
-def shock_sweep(x, Phi, prob, nt, shock_times, shocks, **kw):
-    """every (t_s, shock) combination; shocks: k-by-d.  Returns a list of shock_rollout dicts (batched over x)."""
+def _on_shared_grid(tspan, nt, times):
+    """Which shock times lie on ONE step grid from tspan[0]?  Segment 1 of a shocked rollout takes nShock = int(t_s nt) steps of
+    (t_s - t0) / nShock; for t_s = 0.1, 0.2, ... and nt = 50 that is the same h = 0.02 for every t_s to the last bit or two, so the unshocked
+    trajectory up to the LARGEST t_s contains every shorter segment 1.  Returns (T, N, h, [nShock_k or None per time])."""
+    t0 = float(tspan[0])
+    ok = [(float(t), int(float(t) * nt)) for t in times]
+    cand = [(t, k) for t, k in ok if 1 <= k <= nt]
+    if not cand:
+        return None, 0, 0.0, [None] * len(ok)
+    T, N = max(cand)
+    h = (T - t0) / N
+    on = [k if (1 <= k <= nt and abs(t0 + k * h - t) <= 4e-16 * k * max(1.0, abs(t))) else None for t, k in ok]
+    return T, N, h, on
+
+
+def shock_sweep(x, Phi, prob, nt, shock_times, shocks, tspan=(0.0, 1.0), alph=None, stepper="rk4", group=None, gather=False, shared=True):
+    """Every (t_s, shock) combination; shocks: k-by-d.  Returns a list of shock_rollout dicts (batched over x), t_s-major.
+
+    BASELINE config 5 (the shock-eval sweep) as the reference's code path would run it (src/plotter.py:815-824 once per t_s) integrates the
+    same unshocked trajectory from t0 again for every shock time.  Here (round 5, single precision on one rank):
+      * the unshocked trajectory is integrated ONCE, to the largest shock time, with trajectories and controls kept; the segment 1 of every
+        t_s that lies on that step grid (_on_shared_grid: all of 0.1 ... 0.9 at nt = 50) is its prefix -- equal to the per-t_s segment to
+        the state tolerance (their step sizes differ in the last bit; tests/test_hip_parity.py compares) -- 459 -> 279 steps;
+      * the second segments of ALL (t_s, shock) pairs run as ONE launch over (pair, row) tiles (nocf_rollout_segments_f32: per-segment start
+        time, step count and first output slot), so 9 x 512 rows fill the chip where one 512-row segment occupies an eighth of it, and the
+        kernel writes each pair's shocked trajectory straight behind its copy of the unshocked prefix: `traj` / `ctrl` are views, not cats;
+      * the costs of every segment 1 (running integrals from the trajectory's cost columns, terminal terms from one batched Phi / grad Phi
+        call at (z(t_s), t_s): src/OCflow.py:58-90) and of every segment 2 are formed for all pairs at once.
+    Shock times off the grid, double precision, row-sharded sweeps (`group`) and networks without a segment-taking kernel run
+    shock_rollout per pair, as before (shared=False forces that)."""
+    alph = list(Phi.alph if alph is None else alph)
+    times = [float(t) for t in shock_times]
+    K = int(shocks.shape[0])
+    T, N, h, on = _on_shared_grid(tspan, nt, times)
+    use = (shared and group is None and x.dtype == torch.float32 and x.is_cuda and len(times) * K >= 2
+           and x.shape[0] % 16 == 0 and any(k is not None for k in on))
+    fast = {}
+    if use:
+        fast = _sweep_shared(x, Phi, prob, nt, [(i, t, on[i]) for i, t in enumerate(times) if on[i] is not None], shocks, T, N,
+                             tspan, alph, stepper) or {}
     out = []
-    for t_s in shock_times:
-        for k in range(shocks.shape[0]):
-            res = shock_rollout(x, Phi, prob, nt, float(t_s), shocks[k:k + 1], **kw)
-            res["t_s"], res["shock_index"] = float(t_s), k
+    for i, t_s in enumerate(times):
+        for k in range(K):
+            res = fast.get((i, k))
+            if res is None:
+                res = shock_rollout(x, Phi, prob, nt, t_s, shocks[k:k + 1], tspan=tspan, alph=alph, stepper=stepper, group=group, gather=gather)
+            res["t_s"], res["shock_index"] = t_s, k
             out.append(res)
     return out
+
+
+def _means(sums, alph):
+    """[P, 8] sums -> list of (Jc, cs) per row: the formula of costs_from_sums for many segments at once (a handful of launches in all)"""
+    means = sums[:, :7] / sums[:, 7:8]
+    Jc = means[:, 0] + alph[0] * means[:, 1] + alph[3] * means[:, 2] + alph[4] * means[:, 3] + alph[5] * means[:, 4]
+    return [(Jc[p], [means[p, j] for j in range(7)]) for p in range(sums.shape[0])]
+
+
+def _sweep_shared(x, Phi, prob, nt, on_grid, shocks, T, N, tspan, alph, stepper):
+    """the shared-prefix sweep of shock_sweep; returns {(time index, shock index): result dict} or None (no segment kernel for this shape)"""
+    n, d = x.shape
+    K = int(shocks.shape[0])
+    shocks = torch.as_tensor(shocks, dtype=x.dtype, device=x.device)
+    pairs = [(i, t, ns, k) for (i, t, ns) in on_grid for k in range(K)]
+    with torch.no_grad():
+        # (1) the unshocked trajectory, once
+        _, _, zF, cF = _oc._launch(x, Phi, prob, [tspan[0], T], N, stepper, alph, True)           # [N+1, n, d+4], [N+1, n, a]
+        cdim = cF.shape[2]
+        res = {}
+        # costs of every segment 1: running integrals at its end + the terminal terms at (z(t_s), t_s)
+        ends = torch.stack([zF[ns] for (_, _, ns) in on_grid])                                   # [S, n, d+4]
+        S = ends.shape[0]
+        tcol = torch.tensor([t for (_, t, _) in on_grid], dtype=x.dtype, device=x.device).view(S, 1, 1).expand(S, n, 1)
+        s_in = torch.cat((ends[:, :, :d], tcol), dim=2).reshape(S * n, d + 1).contiguous()
+        phi1 = Phi._value_f32(s_in).view(S, n)
+        g1 = Phi._grad_f32(s_in).view(S, n, d + 1)
+        resid = ends[:, :, :d] - prob.xtarget.to(x.dtype).view(1, 1, d)                          # ocG (src/OCflow.py:97-101)
+        cG = 0.5 * (resid * resid).sum(dim=2)
+        a0 = float(alph[0])
+        sums1 = torch.stack((ends[:, :, d].sum(1), cG.sum(1), ends[:, :, d + 1].sum(1), (phi1 - a0 * cG).abs().sum(1),
+                             (g1[:, :, :d] - a0 * resid).abs().sum(dim=(1, 2)), ends[:, :, d + 2].sum(1), ends[:, :, d + 3].sum(1),
+                             torch.full((S,), float(n), dtype=x.dtype, device=x.device)), dim=1)  # [S, 8]
+        costs1 = _means(sums1, alph)
+        # (2) all second segments: MAX_SEGMENTS pairs per launch
+        for c0 in range(0, len(pairs), _oc.MAX_SEGMENTS):
+            chunk = pairs[c0:c0 + _oc.MAX_SEGMENTS]
+            P = len(chunk)
+            xs = torch.stack([zF[ns, :, :d] + shocks[k:k + 1] for (_, _, ns, k) in chunk]).reshape(P * n, d).contiguous()
+            Z = torch.empty(nt + 3, P * n, d + 4, dtype=x.dtype, device=x.device)
+            Cc = torch.empty(nt + 3, P * n, cdim, dtype=x.dtype, device=x.device)
+            # every pair's copy of the unshocked prefix (slots beyond its nShock are overwritten by its second segment)
+            Z[:N + 1].view(N + 1, P, n, d + 4).copy_(zF.unsqueeze(1).expand(N + 1, P, n, d + 4))
+            Cc[:N + 1].view(N + 1, P, n, cdim).copy_(cF.unsqueeze(1).expand(N + 1, P, n, cdim))
+            got = _oc._launch_segments(xs, Phi, prob, [t for (_, t, _, _) in chunk], tspan[1], [1 + nt - ns for (_, _, ns, _) in chunk], n,
+                                       stepper, alph, slot0s=[ns + 1 for (_, _, ns, _) in chunk], zFull=Z, ctrlFull=Cc)
+            if got is None:
+                return None
+            _, sums2, _, _ = got
+            costs2 = _means(sums2, alph)
+            si = {i: j for j, (i, _, _) in enumerate(on_grid)}
+            for p, (i, t, ns, k) in enumerate(chunk):
+                res[(i, k)] = {"traj": Z[:, p * n:(p + 1) * n, :d].permute(1, 2, 0), "ctrl": Cc[:, p * n:(p + 1) * n, :].permute(1, 2, 0),
+                               "costs1": costs1[si[i]], "costs2": costs2[p], "nShock": ns, "x_shocked": xs[p * n:(p + 1) * n]}
+        _lib.check_errors(sync=True)        # results that are consumed on the host (plots, files): a failed launch must raise here
+    return res

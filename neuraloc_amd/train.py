@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -134,8 +135,11 @@ class _OCflowTrain(torch.autograd.Function):
             # Training tape (wide two-layer networks on the split-role kernel): the recording forward keeps what autograd would keep of the
             # unrolled graph -- u0, tanh(o), tanh(q), a, grad Phi and three scalars of every evaluation, the terminal one included, 2.9 GB for
             # swarm50 -- and the backward is the split-role adjoint (csrc/nocf_duo_bwd.inc).  NOCF_DUO_BWD=0: the per-tile adjoint below.
-            ntape = int(L.nocf_tape_floats(int(d), int(net.m), int(net.nTh), int(n), int(nt), _STEPPERS[stepper])) \
-                if hasattr(L, "nocf_tape_floats") and os.environ.get("NOCF_ACT_REC", "1") not in ("0", "") else 0
+            # (nocf_tape_floats knows the network's shape only: the split-role ADJOINT also needs a point-agent problem and r <= 10 -- asked
+            # here, so that a shape the tape cannot serve takes the activation-record path below instead of holding 2.9 GB for nothing)
+            tape_ok = (hasattr(L, "nocf_tape_floats") and os.environ.get("NOCF_ACT_REC", "1") not in ("0", "")
+                       and prob_st.kind != _lib.PROB_QUADCOPTER and phi_st.r <= 10)
+            ntape = int(L.nocf_tape_floats(int(d), int(net.m), int(net.nTh), int(n), int(nt), _STEPPERS[stepper])) if tape_ok else 0
             tape = None
             if ntape:
                 try:
@@ -153,8 +157,8 @@ class _OCflowTrain(torch.autograd.Function):
                 _lib.check(rc, "nocf_rollout_tape_f32")
                 if recorded.value:
                     ctx.tape = tape
-                else:                                             # another kernel ran (problem class, residency): plain stage inputs
-                    s_all = s_all[:nt * nstage]
+                else:                                             # another kernel ran (residency, a knob): no tape -- the forward is
+                    tape = None                                   # repeated below WITH the activation record that kernel can write
         if tape is not None:
             return _OCflowTrain._forward_tail(ctx, L, dev, net, prob, tspan, nt, stepper, alph, n_total, group, n, sums, s_all, z_out)
         s_all = torch.empty(nt * nstage, n, d + 1, device=dev)
@@ -204,6 +208,7 @@ class _OCflowTrain(torch.autograd.Function):
         return Jc, means.detach()
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gJ, _gmeans):
         s_all, z_out = ctx.saved_tensors
         net, prob, nt, alph = ctx.net, ctx.prob, ctx.nt, ctx.alph
@@ -406,6 +411,7 @@ class _OCflowTrain64(torch.autograd.Function):
         return Jc, means.detach()
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gJ, _gmeans):
         s_all, z_out = ctx.saved_tensors
         net, prob, nt, alph = ctx.net, ctx.prob, ctx.nt, ctx.alph

@@ -20,6 +20,11 @@ from oracle import ocflow_oracle as orc
 from util_hip import count_off, full_states, make_net, make_oracle, make_prob
 
 pytestmark = pytest.mark.gpu
+def load_golden_by_name(name):
+    from conftest import load_golden
+    return load_golden(name)
+
+
 DEV = torch.device("cuda:0")
 
 
@@ -260,6 +265,63 @@ def test_shock_rollout_matches_two_reference_style_segments(golden_pretrained):
     assert bad == 0, f"{g.name}: {bad} shocked-trajectory entries off (worst {worst:g})"
     with pytest.raises(ValueError):
         shock_rollout(x.to(DEV), net, prob, nt, 0.01, shock.to(DEV))      # nShock = 0: the reference divides by zero
+
+
+@pytest.mark.parametrize("name,n", [("singlequad", 48), ("singlequad", 4096), ("softcorridor", 32), ("swarm50", 16)])
+def test_shock_sweep_with_the_shared_prefix_matches_per_shock_time_rollouts_and_the_oracle(name, n, monkeypatch):
+    """BASELINE config 5 (shock-eval sweep).  shock_sweep integrates the unshocked trajectory ONCE to the largest shock time and runs all
+    second segments in one launch (nocf_rollout_segments_f32; singlequad) or one by one (networks without a segment kernel); every
+    (t_s, shock) pair must equal the reference-style pair of rollouts of shock_rollout (src/plotter.py:815-824: segment 1 re-integrated
+    from t0 with its own h = t_s / int(t_s nt)) to the stated STATE tolerance 1e-4 + 1e-5 |ref| -- the shared prefix steps with
+    h = T / int(T nt), equal to every segment's own h to the last bit or two -- and the small case also equals the oracle.  A shock time
+    off the shared grid (0.33 at nt = 50: 16 steps of 0.020625) takes the per-time path inside the same sweep."""
+    from neuraloc_amd.shock import shock_rollout, shock_sweep, _on_shared_grid
+    from neuraloc_amd import OCflow as _pkg_fn                                        # noqa: F401
+    g = load_golden_by_name(name)
+    net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
+    d, nt = g.meta["d"], 50 if name != "swarm50" else 20
+    x = (full_states(g, 7)[:n] if n > g.t("x").shape[0] else g.t("x")[:n]).to(DEV)
+    times = [0.1 * k for k in range(1, 10)] + ([0.33] if n < 100 else [])
+    T, N, h, on = _on_shared_grid((0.0, 1.0), nt, times)
+    assert N == int(0.9 * nt) and all(k is not None for k in on[:9]) and (len(on) == 9 or on[9] is None)
+    shocks = torch.zeros(2 if n < 100 else 1, d, device=DEV)
+    shocks[0, 0:3] = torch.tensor([0.5, -0.5, 0.25])[: min(3, d)]
+    if shocks.shape[0] > 1:
+        shocks[1, :] = 0.02
+    launches = []
+    import neuraloc_amd.OCflow as ocm
+    real = ocm._launch_segments
+    monkeypatch.setattr(ocm, "_launch_segments", lambda *a, **k: (launches.append(len(a[3])), real(*a, **k))[1])
+    got = shock_sweep(x, net, prob, nt, times, shocks, alph=g.meta["alph"])
+    assert len(got) == len(times) * shocks.shape[0]
+    kern = _lib.lib().nocf_last_rollout_kernel().decode()
+    if name == "singlequad":
+        assert launches and sum(launches) == 9 * shocks.shape[0], launches              # all on-grid pairs went through the segment launches
+        assert max(launches) <= 16
+    P, S = make_oracle(g, training=False)
+    for r in got:
+        ref = shock_rollout(x, net, prob, nt, r["t_s"], shocks[r["shock_index"]:r["shock_index"] + 1], alph=g.meta["alph"])
+        assert r["nShock"] == ref["nShock"] and r["traj"].shape == ref["traj"].shape == (n, d, nt + 3)
+        bad, worst = count_off(r["traj"].cpu(), ref["traj"].cpu(), 1e-5, 1e-4)
+        assert bad == 0, f"{name} t_s={r['t_s']}: {bad} trajectory entries off (worst {worst:g})"
+        cs = ref["ctrl"].abs().max().item()
+        assert (r["ctrl"] - ref["ctrl"]).abs().max().item() <= 1e-4 * cs + 1e-4, f"{name} t_s={r['t_s']}: controls"
+        assert torch.allclose(r["x_shocked"], ref["x_shocked"], rtol=1e-5, atol=1e-4)
+        for key in ("costs1", "costs2"):
+            assert abs(float(r[key][0]) - float(ref[key][0])) <= 2e-4 * abs(float(ref[key][0])) + 1e-6, (name, r["t_s"], key)
+            for j in range(7):
+                a, b = float(r[key][1][j]), float(ref[key][1][j])
+                assert abs(a - b) <= 2e-4 * abs(b) + 1e-5, (name, r["t_s"], key, j, a, b)
+        if n <= 48 and r["shock_index"] == 0 and abs(r["t_s"] - 0.5) < 1e-9:          # ... and the oracle, on one pair
+            nS = int(r["t_s"] * nt)
+            with torch.no_grad():
+                z1, _ = orc.rollout(x.cpu(), P, S, [0.0, r["t_s"]], nS, "rk4", g.meta["alph"], intermediates=True)
+                xs = z1[:, :d, -1] + shocks[0:1].cpu()
+                z2, _ = orc.rollout(xs, P, S, [r["t_s"], 1.0], 1 + nt - nS, "rk4", g.meta["alph"], intermediates=True)
+            want = torch.cat((z1[:, :d, :], z2[:, :d, :]), dim=2)
+            bad, worst = count_off(r["traj"].cpu(), want, 1e-5, 1e-4)
+            assert bad == 0, f"{name}: {bad} entries off the oracle (worst {worst:g})"
+    assert kern.startswith("rollout_")
 
 
 # ---- every problem initProb knows (15 names), small deterministic nets, both modes: HIP vs the oracle
