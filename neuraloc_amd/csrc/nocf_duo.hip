@@ -97,20 +97,25 @@ enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P =
 // twice the workgroups per tile.  Where a batch has fewer tiles than the chip has CU pairs (n <= 256 rows: the 4- and 8-GPU shards of
 // n_train = 1024) this is what uses the idle half of the chip; with several tiles per group it shortens every link of the dependency
 // chain that the two roles' tiles interleave on.  An own sample belongs to one member: SPM = 16 / G per member and tile.
-template <int G_> struct DuoCfg {
+// Width (round 5): KBM = m / 16.  m = 512 (KBM = 32) runs with 8 or 16 members; m = 256 (KBM = 16) with FOUR members of 64 hidden units --
+// the default form's member (one feature tile and the whole contraction per wave, 64 AccVGPRs of resident weights instead of 128), 8 workgroups
+// per tile, four own samples per member and tile (every wave owns one).  Evaluation only for now (training of such networks: the per-tile kernels).
+template <int G_, int KBM_ = DU_KBM> struct DuoCfg {
     static constexpr int G = G_;
-    static constexpr int HPM = 64 * DU_G / G_;      // hidden units per member
+    static constexpr int KBM = KBM_;                // 16-wide k-blocks of the hidden width
+    static constexpr int M = 16 * KBM_;             // hidden width
+    static constexpr int HPM = M / G_;              // hidden units per member
     static constexpr int MTM = HPM / 16;            // feature tiles per member
     static constexpr int KS = 4 / MTM;              // waves that share a feature tile (each takes 1 / KS of the contraction)
     static constexpr int SPM = 16 / G_;             // own samples per member and tile
-    static constexpr int KBW = DU_KBM / KS;         // k-blocks of the hidden width per wave (P2, P3)
+    static constexpr int KBW = KBM_ / KS;           // k-blocks of the hidden width per wave (P2, P3)
     static constexpr int KB1 = DU_KBD / KS;         // k-blocks of d + 1 per wave (P1)
     static constexpr int WPG = 2 * G_;              // workgroups per group
-    static_assert(G_ == 8 || G_ == 16, "members per group");
+    static_assert((KBM_ == DU_KBM && (G_ == 8 || G_ == 16)) || (KBM_ == 16 && G_ == 4), "members per group / width");
 };
 
 struct DuoPlan {
-    int d, D1, r, nAg, NT, ngroups, spin_max, fast, G;
+    int d, D1, r, nAg, NT, ngroups, spin_max, fast, G, KBM;
     float hN, cb;
     int mapmode, ldsFloats;
     int dbg, dw;                   // dw: the adjoint with the two weight-gradient roles (32 workgroups per group)
@@ -139,9 +144,9 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
         const uint4 sen = make_uint4(DU_SENT, DU_SENT, DU_SENT, DU_SENT);
         for (long i = gid_; i < nx4; i += stride_) x4[i] = sen;
     }
-    const int m = 64 * DU_G, D1 = dp.D1;
-    // (the geometry of DuoCfg at run time: one pack kernel for both forms; every image has the same size in both)
-    const int G = dp.G, HPM = m / G, MTM = HPM / 16, KS = 4 / MTM, KBW = DU_KBM / KS, KB1 = DU_KBD / KS;
+    const int m = 16 * dp.KBM, D1 = dp.D1;
+    // (the geometry of DuoCfg at run time: one pack kernel for all forms; every image has the same size in both forms of a width)
+    const int G = dp.G, HPM = m / G, MTM = HPM / 16, KS = 4 / MTM, KBW = dp.KBM / KS, KB1 = DU_KBD / KS;
     const long nW = (long)G * 4 * KBW * 64, nK1 = (long)G * 4 * KB1 * 64, nK4 = (long)G * DU_KBD * MTM * 64;
     const long total = 2 * nW + nK1 + nK4;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -473,8 +478,9 @@ __device__ __forceinline__ DXPar du_x_params(const DevProb& pb, int PD) {
 // [2 N entries][4 floats] (entry i and i + N are the same agent, the fourth float is padding): the partner (a + j) mod N is entry
 // a + j -- no wrap, one ds_read_b128 per partner, consecutive lanes read consecutive entries.  Half 0 adds the obstacle terms.
 // Straight-line selects, no per-pair branches; every unordered pair is counted once.  Returns this lane's partial sums.
-// (quarters: the partner range in FOUR parts, `half` = 0..3 -- the fine form has one own sample per member and gives it all four waves)
-template <int PD, bool QUARTERS = false>
+// (NP: the partner range in NP parts, `half` = 0 .. NP - 1: two waves per own sample in the default form, four in the fine form -- one own
+// sample per member --, one with four own samples per member, m = 256)
+template <int PD, int NP = 2>
 __device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, int x4 /* LDS float4 index of the sample's entries */, int lane, int half,
                                           float& qacc, float& wacc) {
     const int N = xp.N;
@@ -498,7 +504,8 @@ __device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, in
         return;
     }
     int jlo = half ? xp.Jh + 1 : 1, jhi = half ? xp.JJ : xp.Jh;                 // partners jlo..jhi (inclusive)
-    if (QUARTERS) { const int Jq = (xp.JJ + 3) >> 2; jlo = half * Jq + 1; jhi = (half + 1) * Jq < xp.JJ ? (half + 1) * Jq : xp.JJ; }
+    if (NP == 4) { const int Jq = (xp.JJ + 3) >> 2; jlo = half * Jq + 1; jhi = (half + 1) * Jq < xp.JJ ? (half + 1) * Jq : xp.JJ; }
+    if (NP == 1) { jlo = 1; jhi = xp.JJ; }
     const bool actlow = act & (a < (N >> 1));                                   // the opposite agent (even N) counts from the lower half only
     constexpr int XW = 5;                                   // partners per round (their LDS reads are in flight together)
     for (int j = jlo; j <= jhi; j += XW) {
@@ -529,11 +536,12 @@ __device__ __forceinline__ void du_x_wave(const DevProb& pb, const DXPar& xp, in
 // byte offsets of the exchange kinds inside a group's area (functions of NT), all pinned in scalar registers by the kernel
 struct DXOff { int S, U, T, V, G, Q, P; };
 // (bwd: the adjoint's layout -- the Q area holds the physics term of two own samples per member, 2 x 160 floats, instead of 2 x 2 scalars)
-__host__ __device__ inline long duo_x_layout(int NT, DXOff* o, bool bwd = false, int G = DU_G) {
+__host__ __device__ inline long duo_x_layout(int NT, DXOff* o, bool bwd = false, int G = DU_G, int KBM = DU_KBM) {
     long x = 0;
     auto take = [&](long nfl) { const long at = x; x += (nfl + 63) / 64 * 64; return at; };
-    const long s = take(2L * NT * DU_KBD * 256), u = take(2L * NT * DU_KBM * 256), t = take(2L * NT * DU_KBM * 256), v = take(2L * NT * DU_KBM * 256);
-    const long gg = take(2L * NT * G * DU_KBD * 256), q = take(3L * NT * G * (bwd ? 320 : 4)), p = take((long)NT * DU_G * 4 * 16);
+    const long s = take(2L * NT * DU_KBD * 256), u = take(2L * NT * KBM * 256), t = take(2L * NT * KBM * 256), v = take(2L * NT * KBM * 256);
+    // (cost scalars: 2 floats per own sample = 32 per tile whatever the form; the adjoint: 160 per own sample)
+    const long gg = take(2L * NT * G * DU_KBD * 256), q = take(3L * NT * 32 * (bwd ? 80 : 1)), p = take((long)NT * DU_G * 4 * 16);
     if (o) { o->S = (int)(s * 4); o->U = (int)(u * 4); o->T = (int)(t * 4); o->V = (int)(v * 4); o->G = (int)(gg * 4); o->Q = (int)(q * 4); o->P = (int)(p * 4); }
     return x;                                      // floats per group
 }
@@ -542,10 +550,11 @@ struct DuoRun { long row0, n_total; };             // rows of this launch inside
 
 // REC: the training variant also stores every stage input (RollArgs::sAll); ZF: intermediates (trajectories and controls, one more
 // evaluation per step); the plain evaluation variant carries no trace of either
-template <int PD, bool REC, bool ZF, int GM = DU_G>
+template <int PD, bool REC, bool ZF, int GM = DU_G, int KBMT = DU_KBM>
 __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __restrict__ dpp, DevProb pb, float* ws, RollArgs ra, DuoRun rr) {
-    typedef DuoCfg<GM> CF;
+    typedef DuoCfg<GM, KBMT> CF;
     constexpr int G = CF::G, MTM = CF::MTM, KS = CF::KS, SPM = CF::SPM, KBW = CF::KBW, KB1 = CF::KB1, WPG = CF::WPG, HPM = CF::HPM;
+    constexpr int KBM = CF::KBM, MW = CF::M;
     // LDS of the fine form: the waves' partial sums [4 waves][64 lanes][4] (role A: in front of the per-sample blocks; role B: in the half of
     // the K4 region that its half-sized image leaves free)
     constexpr int DAPX = DA_T, DAPW = DA_T + (KS > 1 ? 1024 : 0), DAT = DAPW + 4 * DPW_WORDS, DBPX = DB_K4 + DU_KBD * MTM * 256, DBPW = DB_END;
@@ -620,7 +629,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     const int d = dp.d;
     const float hN = dp.hN;
     DXOff xo;
-    (void)duo_x_layout(NT, &xo, false, G);
+    (void)duo_x_layout(NT, &xo, false, G, KBM);
     int xS = xo.S, xU = xo.U, xT = xo.T, xV = xo.V, xG = xo.G, xQ = xo.Q, xP = xo.P;
     DU_PIN(xS); DU_PIN(xU); DU_PIN(xT); DU_PIN(xV); DU_PIN(xG); DU_PIN(xQ); DU_PIN(xP);
     DCtx g;
@@ -685,7 +694,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         }
         for (int i = tid; i < 16 * DU_DP; i += 256) lds[DA_A + i] = ws[dp.oA + i];
         if (tid < DU_DP) lds[DA_CW + tid] = ws[dp.oCW + tid];
-        if (tid < 192 && (tid & 63) < HPM) lds[DA_VEC + tid] = ws[dp.oVec + (tid >> 6) * 64 * DU_G + member * HPM + (tid & 63)];
+        if (tid < 192 && (tid & 63) < HPM) lds[DA_VEC + tid] = ws[dp.oVec + (tid >> 6) * MW + member * HPM + (tid & 63)];
         for (int i = tid; i < SPM * NT * DS_STRIDE; i += 256) lds[DAT + i] = 0.f;
         du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DAPW, wave, lane);     // (one tile per group: measured, see DCtx; dbg bit 16 forces it on)
         __syncthreads();
@@ -756,7 +765,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             if (!have) g_request(s, parG, pv);
             unsigned qa = 0, qb = 0;
             if (pst != nstage) {   // the cost scalars of this sample ride along (consumed by own_costs, behind P2): their round trip is off the critical path
-                const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((e - 1) % 3) * NT + t) * G + member) * 4 + 2 * j) * 4, 16);
+                const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((e - 1) % 3) * NT + t) * G + member) * (2 * SPM) + 2 * j) * 4, 16);
                 qa = v2[0]; qb = v2[1];
             }
             const f32x4 gs = gather_g(s, parG, true, pv);
@@ -815,7 +824,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 }
                 // ... and, with an activation record, grad Phi of evaluation e-1 (index e-2)
                 if (REC && ra.act && own_row(t, j) < ra.n) {
-                    float* dst = ra.act + 4 * ra.actRows * (64 * DU_G) + (((long)(e - 2)) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 1);
+                    float* dst = ra.act + 4 * ra.actRows * MW + (((long)(e - 2)) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 1);
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 <= d) dst[pi + e4] = gs[e4];
                 }
@@ -843,7 +852,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
             float q_ = 0.f, w_ = 0.f;
             {
-                const int ob = xQ + (((((e - 1) % 3) * NT + t) * G + member) * 4 + 2 * j) * 4;
+                const int ob = xQ + (((((e - 1) % 3) * NT + t) * G + member) * (2 * SPM) + 2 * j) * 4;
                 int spins = 0;
                 while (true) {
                     if (!have) { const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, ob, 16); qa = v2[0]; qb = v2[1]; }
@@ -958,8 +967,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const double te = fin ? ra.t1 : ((nstage == 1 || st == 0 || st == nstage) ? tk : (st == 3 ? tk + hsd : tk + hsd / 2));
                 // tile after tile: while this workgroup multiplies tile t, role B works on the tile before it
                 for (int t = 0; t < NT; ++t) {
-                    const int s0 = SPM * t, s1 = SPM * t + SPM - 1;
-                    const int sown = ((s0 & 3) == wave) ? s0 : (((s1 & 3) == wave) ? s1 : -1);      // this wave's own sample of the tile, if any
+                    int sown = -1;                                  // this wave's own sample of the tile, if any: sample s belongs to wave s & 3
+#pragma unroll
+                    for (int j = 0; j < SPM; ++j) if (((SPM * t + j) & 3) == wave) sown = SPM * t + j;
                     if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, false, pf);
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
@@ -968,6 +978,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // takes thousands of cycles that every member of the group then waits for: 5.54 -> 5.29 ms)
                     if (e > 1) {
                         if (SPM == 2) { if (sown < 0) du_gather2<DU_KBD>(g, (wave ^ (wave >> 1)) & 1, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t); }
+                        else if (SPM == 4) du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t);      // (every wave is an owner)
                         else { const int wh = ((wave - (t & 3)) & 3) - 1; if (wh >= 0 && wh < 2) du_gather2<DU_KBD>(g, wh, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t); }
                     } else du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
                     __syncthreads();
@@ -980,7 +991,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                                 // fine form: the slots of the previous evaluation are reset HERE (S of this evaluation is staged: every reader is
                                 // done), a whole product + hop earlier than in the default form: P2 is only 64 MFMAs long there and its vmcnt(0) in front
                                 // of the V store would wait for these acknowledgements (H1 is unchanged: that wait still lies between them and V)
-                                const int fr = (((par ^ 1) * NT + t) * DU_KBM + MTM * member + ft) * 1024;
+                                const int fr = (((par ^ 1) * NT + t) * KBM + MTM * member + ft) * 1024;
                                 if (kh == 0) { du_st_sent(g, vb, xU + fr); du_st_sent(g, vb, xV + fr); } else du_st_sent(g, vb, xT + fr);
                             }
                         });
@@ -996,16 +1007,16 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         f32x4 sg, th;
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) { float s_, t_; act_pair(acc[e4] + b0v[e4], s_, t_); sg[e4] = s_; th[e4] = t_; }
-                        const int fo = ((par * NT + t) * DU_KBM + MTM * member + ft) * 1024;
+                        const int fo = ((par * NT + t) * KBM + MTM * member + ft) * 1024;
                         // (fine form: both waves of a feature tile hold o; one publishes sigma(o), the other tanh(o))
                         if (KS == 1 || kh == 0) du_st(g, vb, xU + fo, sg);
                         if (KS == 1 || kh == 1) du_st(g, vb, xT + fo, th);
                         if (REC && ra.act && (!fin || ra.tapeSc)) {    // activation record: 4 features of sample lane & 15 (64-byte runs per sample)
                             const long rw = rowg + 16 * t + (lane & 15);
                             if (rw < ra.n) {
-                                float* dst = ra.act + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G) + HPM * member + 16 * ft + 4 * slot;
+                                float* dst = ra.act + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * MW + HPM * member + 16 * ft + 4 * slot;
                                 if (KS == 1 || kh == 0) *reinterpret_cast<float4*>(dst) = make_float4(sg[0], sg[1], sg[2], sg[3]);
-                                if (KS == 1 || kh == 1) *reinterpret_cast<float4*>(dst + ra.actRows * (64 * DU_G)) = make_float4(th[0], th[1], th[2], th[3]);
+                                if (KS == 1 || kh == 1) *reinterpret_cast<float4*>(dst + ra.actRows * MW) = make_float4(th[0], th[1], th[2], th[3]);
                             }
                         }
                     }
@@ -1018,14 +1029,14 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // (the members of a group finish P1 within a few hundred clocks of each other, and a wave arrives here right behind its own U
                     // store: a poll issued at once reaches L2 before the slowest member's fragment and costs a whole second round trip)
                     for (int i = 0; i < g.udelay; ++i) __builtin_amdgcn_s_sleep(1);
-                    du_gather<DU_KBM>(g, wave, lane, xU + ((par * NT + t) * DU_KBM) * 1024, DA_UF >> 2, DUK_U);
+                    du_gather<KBM>(g, wave, lane, xU + ((par * NT + t) * KBM) * 1024, DA_UF >> 2, DUK_U);
                     __syncthreads();
                     DTL(40 * t + 10);
                     {
                         // the slots of the previous evaluation (every reader is done: S of this evaluation exists).  Here, not in the P1
                         // epilogue: no load of this wave waits behind them, and the GEMM covers their acknowledgement (V one phase early:
                         // header, H1)
-                        const int fr = (((par ^ 1) * NT + t) * DU_KBM + MTM * member + ft) * 1024;
+                        const int fr = (((par ^ 1) * NT + t) * KBM + MTM * member + ft) * 1024;
                         float4 b1s, wvs;
                         auto resets = [&](int kb) {
                             if (KS == 1 && kb == 1) { du_st_sent(g, vb, xU + fr); du_st_sent(g, vb, xT + fr); du_st_sent(g, vb, xV + fr); }      // (fine form: in P1)
@@ -1054,13 +1065,13 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         asm volatile("" : "+v"(v));
                         DTL(40 * t + 17);
 #endif
-                        if (KS == 1 || kh == 0) du_st(g, vb, xV + ((par * NT + t) * DU_KBM + MTM * member + ft) * 1024, v);
+                        if (KS == 1 || kh == 0) du_st(g, vb, xV + ((par * NT + t) * KBM + MTM * member + ft) * 1024, v);
                         du_anchor(g, t, lane);                  // (predictive waiting: this wave's next waits for tile t count from here)
                         DTL(40 * t + 12);
                         if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 0)) {    // activation record: tanh(q)
                             const long rw = rowg + 16 * t + (lane & 15);
                             if (rw < ra.n)
-                                *reinterpret_cast<float4*>(ra.act + 2 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
+                                *reinterpret_cast<float4*>(ra.act + 2 * ra.actRows * MW + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * MW
                                                            + HPM * member + 16 * ft + 4 * slot) = make_float4(tq[0], tq[1], tq[2], tq[3]);
                         }
                         if (fin && (KS == 1 || kh == 1)) {     // (fine form: the wave that does not publish v takes the value's part)
@@ -1072,7 +1083,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                             for (int e4 = 0; e4 < 4; ++e4) { u1[e4] = u0[e4] + hN * sigma_act(acc[e4] + b1v[e4]); pr += wv[e4] * u1[e4]; }
                             if (REC && ra.tapeU1) {                    // tape: u_1 of the terminal evaluation (the value's dw row)
                                 const long rw = rowg + 16 * t + (lane & 15);
-                                if (rw < ra.n) *reinterpret_cast<float4*>(ra.tapeU1 + (rr.row0 + rw) * (64 * DU_G) + HPM * member + 16 * ft + 4 * slot) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                                if (rw < ra.n) *reinterpret_cast<float4*>(ra.tapeU1 + (rr.row0 + rw) * MW + HPM * member + 16 * ft + 4 * slot) = make_float4(u1[0], u1[1], u1[2], u1[3]);
                             }
                             pr += __shfl_xor(pr, 16); pr += __shfl_xor(pr, 32);
                             if (lane < 16) {
@@ -1115,19 +1126,19 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             {
                 unsigned u = 0;
                 int spins = 0;
-                const int off = xP + ((t * G * MTM + (lane & 31)) * 16 + SPM * member + j) * 4;
+                const int off = xP + ((t * G * MTM + (lane & (G * MTM - 1))) * 16 + SPM * member + j) * 4;
                 while (true) {
                     u = __builtin_amdgcn_raw_buffer_load_b32(g.xrs, off, 0, 16);
                     if (!__any(u == DU_SENT)) break;
                     if (du_spin(g, spins, DUK_P)) break;
                 }
-                ph = sum64(lane < 32 ? __uint_as_float(u) : 0.f);
+                ph = sum64(lane < G * MTM ? __uint_as_float(u) : 0.f);
             }
             const long row = own_row(t, j);
             if (REC && ra.tapeSc && row < ra.n) {               // tape: grad Phi and Phi - alph0 G of the terminal evaluation (block nt * nstage)
                 const long blk = (long)ra.nt * nstage;
                 if (pact) {
-                    float* dst = ra.act + 4 * ra.actRows * (64 * DU_G) + (blk * rr.n_total + rr.row0 + row) * (d + 1);
+                    float* dst = ra.act + 4 * ra.actRows * MW + (blk * rr.n_total + rr.row0 + row) * (d + 1);
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 <= d) dst[pi + e4] = gs[e4];
                 }
@@ -1156,7 +1167,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // role B: x-only cost terms, P3, P4
         // =====================================================================================================
         for (int i = tid; i < DU_KBD * MTM * 64; i += 256) L4[(DB_K4 >> 2) + i] = ws4[dp.oK4 + (long)member * DU_KBD * MTM * 64 + i];
-        if (tid < HPM) lds[DB_VEC + tid] = ws[dp.oVec + 2 * 64 * DU_G + member * HPM + tid];
+        if (tid < HPM) lds[DB_VEC + tid] = ws[dp.oVec + 2 * MW + member * HPM + tid];
         du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DBPW, wave, lane);
         __syncthreads();
         const DXPar xp = du_x_params(pb, PD);
@@ -1174,7 +1185,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 if (stage) {
                     // ================= x-only cost terms of the own samples of tile t at the state of evaluation e =================
                     if (wave < SPM) {                                   // 40 SPM pieces of 16 B: dims 4 l .. 4 l + 3 of own sample j
-                        const int p = tid < 40 * SPM ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, pmt = r_ >> 2, sl = r_ & 3;
+                        const int p = tid < 40 * SPM ? tid : 0, j = p / 40, r_ = p - 40 * j, pmt = r_ >> 2, sl = r_ & 3;
                         const int off = xS + ((par * NT + t) * DU_KBD + pmt) * 1024 + (sl * 16 + SPM * member + j) * 16;
                         u32x4 v = spf;
                         bool have = spf_t == t;                         // requested before the previous tile's P4 stores (see there)
@@ -1204,8 +1215,10 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     {
                         float q_ = 0.f, w_ = 0.f;
                         // (two own samples: wave = (sample, half of the partner range); one: the four waves take a quarter each)
-                        if (SPM == 2) du_x_wave<PD>(pb, xp, (DB_XA >> 2) + (wave & 1) * 128, lane, wave >> 1, q_, w_);
-                        else du_x_wave<PD, true>(pb, xp, DB_XA >> 2, lane, wave, q_, w_);
+                        // (four: wave = sample, the whole range)
+                        if (SPM == 2) du_x_wave<PD, 2>(pb, xp, (DB_XA >> 2) + (wave & 1) * 128, lane, wave >> 1, q_, w_);
+                        else if (SPM == 4) du_x_wave<PD, 1>(pb, xp, (DB_XA >> 2) + wave * 128, lane, 0, q_, w_);
+                        else du_x_wave<PD, 4>(pb, xp, DB_XA >> 2, lane, wave, q_, w_);
                         q_ = sum64(q_); w_ = sum64(w_);
                         if (lane == 0) { lds[DB_XP + 2 * wave] = q_; lds[DB_XP + 2 * wave + 1] = w_; }
                     }
@@ -1214,19 +1227,20 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     if (wave == 0 && lane < SPM) {                      // sample j = lane: the parts in a fixed order
                         float q_, w_;
                         if (SPM == 2) { q_ = lds[DB_XP + 2 * lane] + lds[DB_XP + 2 * (lane + 2)]; w_ = lds[DB_XP + 2 * lane + 1] + lds[DB_XP + 2 * (lane + 2) + 1]; }
+                        else if (SPM == 4) { q_ = lds[DB_XP + 2 * lane]; w_ = lds[DB_XP + 2 * lane + 1]; }
                         else { q_ = (lds[DB_XP] + lds[DB_XP + 2]) + (lds[DB_XP + 4] + lds[DB_XP + 6]); w_ = (lds[DB_XP + 1] + lds[DB_XP + 3]) + (lds[DB_XP + 5] + lds[DB_XP + 7]); }
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 pay = {__float_as_uint(q_), __float_as_uint(w_)};
-                        const int off = xQ + ((((e % 3) * NT + t) * G + member) * 4 + 2 * lane) * 4;          // (three slots: see the reset in P3)
+                        const int off = xQ + ((((e % 3) * NT + t) * G + member) * (2 * SPM) + 2 * lane) * 4;          // (three slots: see the reset in P3)
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(pay, g.xrs, off, 0, 16);      // (the slot is reset below, behind the V gather)
                     }
                     DTL(40 * t + 23);
                 }
                 // ================= P3: a = w + hN K1[:,H_c]^T v ; y = tanh(o) . a =================
-                const int fo = ((par * NT + t) * DU_KBM + MTM * member + ft) * 1024;
+                const int fo = ((par * NT + t) * KBM + MTM * member + ft) * 1024;
                 DTL(40 * t + 24);
-                du_gather<DU_KBM>(g, wave, lane, xV + ((par * NT + t) * DU_KBM) * 1024, DB_VF >> 2, DUK_V, DPW_V, t);
+                du_gather<KBM>(g, wave, lane, xV + ((par * NT + t) * KBM) * 1024, DB_VF >> 2, DUK_V, DPW_V, t);
                 __syncthreads();
                 DTL(40 * t + 25);
                 u32x4 thv = {DU_SENT, DU_SENT, DU_SENT, DU_SENT};
@@ -1249,7 +1263,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     if (wave == 0 && lane < SPM) {
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const u32x2 sen = {DU_SENT, DU_SENT};
-                        const int offr = xQ + (((((e + 1) % 3) * NT + t) * G + member) * 4 + 2 * lane) * 4;
+                        const int offr = xQ + (((((e + 1) % 3) * NT + t) * G + member) * (2 * SPM) + 2 * lane) * 4;
                         if (g.fast) __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b64(sen, g.xrs, offr, 0, 16);
                     }
@@ -1286,7 +1300,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 1)) {        // activation record: a = w + hN K1' v
                         const long rw = rowg + 16 * t + (lane & 15);
                         if (rw < ra.n)
-                            *reinterpret_cast<float4*>(ra.act + 3 * ra.actRows * (64 * DU_G) + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * (64 * DU_G)
+                            *reinterpret_cast<float4*>(ra.act + 3 * ra.actRows * MW + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * MW
                                                        + HPM * member + 16 * ft + 4 * slot) = a4;
                     }
                 }
@@ -1298,7 +1312,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     const int tn = (t + 1 < NT) ? t + 1 : 0, pn = (t + 1 < NT) ? par : (par ^ 1);
                     const int en = (t + 1 < NT) ? e : e + 1;
                     if (en < E && ((en - 1) % nsub) < nstage) {
-                        const int p = tid < 40 * SPM ? tid : 0, j = p >= 40 ? 1 : 0, r_ = p - 40 * j, pmt = r_ >> 2, sl = r_ & 3;
+                        const int p = tid < 40 * SPM ? tid : 0, j = p / 40, r_ = p - 40 * j, pmt = r_ >> 2, sl = r_ & 3;
                         spf = du_ld(g, xS + ((pn * NT + tn) * DU_KBD + pmt) * 1024 + (sl * 16 + SPM * member + j) * 16, 0);
                         spf_t = tn;
                     }
@@ -1403,20 +1417,22 @@ static int du_env_int(const char* name, int dflt) { return nocf_env_int(name, df
 long duo_rows_per_launch(void) { return 32L * 16 * DU_NTMAX; }
 
 // G: members per group of the forward (8: the form of rounds 3-4; 16: the fine form, DuoCfg); the adjoint always runs with 8
+// (m = 256: four members, the forward only; G is then ignored)
 static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false, bool dw = false, int G = DU_G) {
-    if (nTh != 2 || m != 64 * DU_G || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
-    if ((G != DU_G && G != DU_GMAX) || (G != DU_G && (bwd || dw))) return NOCF_E_SHAPE;
+    if (nTh != 2 || (m != 64 * DU_G && m != 256) || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
+    if (m == 256) { if (bwd || dw) return NOCF_E_SHAPE; G = 4; }
+    else if ((G != DU_G && G != DU_GMAX) || (G != DU_G && (bwd || dw))) return NOCF_E_SHAPE;
     DuoPlan dp;
     memset(&dp, 0, sizeof(dp));
-    dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents; dp.G = G;
+    dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents; dp.G = G; dp.KBM = m / 16;
     const long ntiles = (n + 15) / 16;
     dp.ngroups = (int)std::min<long>((dw ? 16 : 32) * DU_G / G, ntiles);     // (512 workgroups fill the chip: 32 groups of 16, 16 groups of 32 (dw, fine form))
     dp.dw = dw ? 1 : 0;
     dp.NT = (int)((ntiles + dp.ngroups - 1) / dp.ngroups);
-    if (dp.NT > DU_NTMAX) return NOCF_E_SHAPE;
+    if (dp.NT > (m == 256 ? 2 : DU_NTMAX)) return NOCF_E_SHAPE;       // (four own samples per member and tile: LDS for two tiles)
     dp.hN = 1.0f;
     if (bwd && r > 10) return NOCF_E_SHAPE;                                        // (the adjoint keeps 10 rows of A in LDS)
-    const int fine = G != DU_G ? 1024 : 0;                                         // (the waves' partial sums: see the kernel)
+    const int fine = G == DU_GMAX ? 1024 : 0;                                      // (the waves' partial sums: see the kernel)
     const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE : DA_T + fine + 4 * DPW_WORDS + (16 / G) * dp.NT * DS_STRIDE, ldsB = DB_END + (bwd ? 0 : 4 * DPW_WORDS);
     dp.ldsFloats = std::max(std::max(ldsA, ldsB), dw ? DC_END : 0);
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
@@ -1426,17 +1442,18 @@ static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, Duo
     dp.oXcc = o; o += 32 * 16;
     dp.oCen = o; o += 8 * 520;                                                    // CU census of the role map (uints)
     o += 32 * 32;                                                                  // progress counters of the weight-gradient roles: [group][2] at oCen + 8 * 520, 64 B apart
-    const long nW = (long)DU_G * 4 * DU_KBM * 64, nK1 = (long)DU_G * 4 * DU_KBD * 64, nK4 = (long)DU_G * DU_KBD * 4 * 64;   // float4s
+    const long gw = m / 64;                                                        // (image sizes depend on the width only)
+    const long nW = gw * 4 * (m / 16) * 64, nK1 = gw * 4 * DU_KBD * 64, nK4 = gw * DU_KBD * 4 * 64;   // float4s
     dp.oW2 = o / 4; o += nW * 4;
     dp.oW3 = o / 4; o += nW * 4;
     dp.oK1 = o / 4; o += nK1 * 4;
     dp.oK4 = o / 4; o += nK4 * 4;
     dp.oA = o; o += 16 * DU_DP;
-    dp.oVec = o; o += 3 * 64 * DU_G;
+    dp.oVec = o; o += 3 * m;
     dp.oCW = o; o += DU_DP;
     o = (o + 63) / 64 * 64;
     dp.oX = o;
-    dp.xStride = duo_x_layout(dp.NT, nullptr, bwd, G);
+    dp.xStride = duo_x_layout(dp.NT, nullptr, bwd, G, dp.KBM);
     *out = dp;
     return 0;
 }
@@ -1450,12 +1467,13 @@ int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size
     size_t b = duo_ws_bytes_of(dp);
     if (make_duo_plan(d, m, nTh, r, n_agents, std::min<long>(n, duo_rows_per_launch()), &db, true) == 0) b = std::max(b, duo_ws_bytes_of(db));   // (the adjoint's exchange area is larger)
     if (make_duo_plan(d, m, nTh, r, n_agents, std::min<long>(n, duo_rows_per_launch()), &db, false, false, DU_GMAX) == 0) b = std::max(b, duo_ws_bytes_of(db));   // (the fine form's partial-gradient area too)
+
     if (bytes) *bytes = b;
     return 0;
 }
 
-template <int PD, bool REC, bool ZF, int GM>
-static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF, GM>); }
+template <int PD, bool REC, bool ZF, int GM, int KBMT = DU_KBM>
+static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF, GM, KBMT>); }
 template <int GM>
 static const void* duo_pick(bool c2, bool rec, bool zf) {
     return c2 ? (rec ? duo_fn<2, true, false, GM>() : (zf ? duo_fn<2, false, true, GM>() : duo_fn<2, false, false, GM>()))
@@ -1475,15 +1493,19 @@ static int duo_pick_G(long n) {
 int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, float* ws, size_t ws_bytes, hipStream_t st,
                const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
     if (pb.kind == NOCF_PROB_QUADCOPTER || (ra_in.zFull && ra_in.sAll)) return 1;
-    const int GM = duo_pick_G(ra_in.n);
-    const long chunk = duo_rows_per_launch() * DU_G / GM;         // (the fine form has half as many groups per launch)
+    const bool narrow = phi->m == 256;                             // four members per group, evaluation only (DuoCfg)
+    if (narrow && (ra_in.sAll || ra_in.zFull)) return 1;
+    const int GM = narrow ? 4 : duo_pick_G(ra_in.n);
+    // (512 workgroups per launch: 32 groups of 16, 16 of 32, 64 of 8; up to four tiles per group, two with four own samples per member)
+    const long chunk = narrow ? duo_rows_per_launch() : duo_rows_per_launch() * DU_G / GM;
     DuoPlan dp0;
     if (make_duo_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, std::min<long>(ra_in.n, chunk), &dp0, false, false, GM) != 0) return 1;
     if (ws_bytes < duo_ws_bytes_of(dp0)) return 1;
     const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
     const bool rec = ra_in.sAll != nullptr;
     const bool zf = ra_in.zFull != nullptr;
-    const void* fk = GM == DU_G ? duo_pick<DU_G>(c2, rec, zf) : duo_pick<DU_GMAX>(c2, rec, zf);
+    const void* fk = narrow ? (c2 ? duo_fn<2, false, false, 4, 16>() : duo_fn<3, false, false, 4, 16>())
+                            : (GM == DU_G ? duo_pick<DU_G>(c2, rec, zf) : duo_pick<DU_GMAX>(c2, rec, zf));
     const int wpg = 2 * GM;
     // residency: all 16 x ngroups workgroups spin on each other, so every one of them must be resident at once: two per CU
     // (256 registers per lane, <= 80 KB LDS).  The grid is checked against what the runtime says fits; the stream must be
