@@ -156,6 +156,17 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * nocf_rollout_f32 that also forms the means: cost_means device [8] = the 7 batch means [L, G, HJt, HJfin, HJgrad, Q, W] and Jc
+ * (src/OCflow.py:80-90; what nocf_cost_means_f32 computes from cost_sums, same arithmetic), written by the launch that reduces the
+ * per-sample table -- for callers with no all-reduce between the sums and the means (one device, the whole batch): one launch less per call.
+ * cost_means nullable; it needs cost_sums.
+ */
+int nocf_rollout_means_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                           double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                           float* z_out, float* persample, float* cost_sums, float* cost_means, float* zFull, float* ctrlFull,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Several rollouts that differ only in their start time and step count, in ONE launch (round 5): the second segments of a shock sweep.
  * The reference's shocked rollout (src/plotter.py:815-824, driven by evalOC.py:113-122) is OCflow on [0, t_s] with int(t_s nt) steps, the
  * shock added to the end state, and OCflow on [t_s, 1] with 1 + nt - int(t_s nt) steps; a sweep over shock times (BASELINE config 5) repeats

@@ -62,8 +62,9 @@ def _launch64(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
     return persample, sums, zFull, ctrlFull
 
 
-def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
-    """run the HIP rollout; returns (persample [n,7], sums [8], zFull_tm, ctrlFull_tm)"""
+def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates, means=None):
+    """run the HIP rollout; returns (persample [n,7], sums [8], zFull_tm, ctrlFull_tm).  means: an 8-float device tensor that the same
+    launch sequence fills with the 7 batch means and Jc (nocf_rollout_means_f32: for callers without an all-reduce behind the sums)"""
     if isinstance(x, torch.Tensor) and x.dtype == torch.float64:
         return _launch64(x, Phi, prob, tspan, nt, stepper, alph, intermediates)
     x = _lib.require_device_f32(x, "x")
@@ -95,15 +96,24 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates):
     alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
     with torch.cuda.device(dev):
         L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents)
-        rc = L.nocf_rollout_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
-                                         float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
-                                         None, _lib.ptr(persample), _lib.ptr(sums),
-                                         _lib.ptr(zFull), _lib.ptr(ctrlFull),
-                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        if means is not None and hasattr(L, "nocf_rollout_means_f32"):
+            rc = L.nocf_rollout_means_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+                                          float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
+                                          None, _lib.ptr(persample), _lib.ptr(sums), _lib.ptr(means),
+                                          _lib.ptr(zFull), _lib.ptr(ctrlFull),
+                                          _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        else:
+            if means is not None:
+                means.fill_(float("nan"))                   # (a per-shape library built before this entry point existed: the caller checks)
+            rc = L.nocf_rollout_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
+                                    float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
+                                    None, _lib.ptr(persample), _lib.ptr(sums),
+                                    _lib.ptr(zFull), _lib.ptr(ctrlFull),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "nocf_rollout_f32")
     _lib.track_rollout_status(L, dev, "OCflow")
     if _lib.duo_guard(L, "OCflow"):
-        return _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates)
+        return _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates, means)
     return persample, sums, zFull, ctrlFull
 
 
@@ -199,6 +209,14 @@ def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0
         if int(nt) < 1:
             raise ValueError("nt must be >= 1")
         return ocflow_train(x, Phi, prob, tspan, nt, stepper, alph)
+    want_means = not (noMean or intermediates) and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32
+    means = torch.empty(8, dtype=torch.float32, device=x.device) if want_means else None
+    if means is not None:
+        persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, False, means)
+        # (the means came with the launch that reduced the per-sample table: no separate nocf_cost_means_f32 launch)
+        if hasattr(_lib.lib(), "nocf_rollout_means_f32"):
+            return means[7], [means[i] for i in range(7)]
+        return costs_from_sums(sums, alph)
     persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates and not noMean)
     if noMean or intermediates:
         # results that are consumed on the host (plots, files): a timed-out exchange must raise HERE, not at the next call

@@ -232,6 +232,12 @@ def _bind(L):
                                    C.c_double, C.c_double, C.c_int32, C.c_int32, fp,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]
+    if hasattr(L, "nocf_rollout_means_f32"):
+        L.nocf_rollout_means_f32.restype = C.c_int
+        L.nocf_rollout_means_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_void_p, C.c_int64,
+                                             C.c_double, C.c_double, C.c_int32, C.c_int32, fp,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]
     if hasattr(L, "nocf_rollout_segments_f32"):
         L.nocf_rollout_segments_f32.restype = C.c_int
         L.nocf_rollout_segments_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_void_p, C.c_int64,

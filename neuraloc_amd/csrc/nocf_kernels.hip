@@ -1360,8 +1360,11 @@ __global__ void __launch_bounds__(512) prob_kernel(DevPlan pl, DevProb pb, const
 }
 
 // deterministic reduction of the per-sample table: 7 column sums (fp64 accumulation, fixed order) + n
+// (means != null: also the 7 means and Jc of cost_means_kernel, same arithmetic on the same rounded sums -- one launch less per call when no
+// all-reduce stands between the sums and the means)
+struct MeanArgs { float* means; float a0, a3, a4, a5; };
 __global__ void __launch_bounds__(256) cost_sum_kernel(float* __restrict__ tab, long n, float* __restrict__ out,
-                                                       const unsigned* __restrict__ err) {
+                                                       const unsigned* __restrict__ err, MeanArgs ma = MeanArgs{nullptr, 0.f, 0.f, 0.f, 0.f}) {
     __shared__ double sh[256 * 7];
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (long row = threadIdx.x; row < n; row += 256)
@@ -1378,6 +1381,15 @@ __global__ void __launch_bounds__(256) cost_sum_kernel(float* __restrict__ tab, 
     // per-sample row (the noMean path returns them); the host raises when it reads the error word (nocf_last_rollout_status_async)
     const bool failed = err && *err;
     if (threadIdx.x == 7) out[7] = failed ? __int_as_float(0x7fc00000) : (float)n;
+    if (ma.means && threadIdx.x < 8) {
+        const float cnt = failed ? __int_as_float(0x7fc00000) : (float)n;
+        const int i = threadIdx.x;
+        if (i < 7) ma.means[i] = (float)sh[i] / cnt;
+        else {
+            const float L = (float)sh[0] / cnt, G = (float)sh[1] / cnt, HJt = (float)sh[2] / cnt, HJfin = (float)sh[3] / cnt, HJgrad = (float)sh[4] / cnt;
+            ma.means[7] = (((L + ma.a0 * G) + ma.a3 * HJt) + ma.a4 * HJfin) + ma.a5 * HJgrad;          // src/OCflow.py:88-90, same order as cost_means_kernel
+        }
+    }
     if (failed) for (long i = threadIdx.x; i < n * 7; i += 256) tab[i] = __int_as_float(0x7fc00000);
 }
 
@@ -1883,7 +1895,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
                         float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
                         void* workspace, size_t workspace_bytes, void* stream, float* s_all,
                         float* act = nullptr, int32_t* act_recorded = nullptr, float* tapeU1 = nullptr, float* tapeSc = nullptr,
-                        const SegTab* seg = nullptr) {
+                        const SegTab* seg = nullptr, float* cost_means = nullptr) {
     if (act_recorded) *act_recorded = 0;
     int rc = check_phi(phi);
     if (rc) return rc;
@@ -1909,6 +1921,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     ra.cdim = nocf_ctrl_dim(prob, phi->d);
     ra.stamps = g_stamp_buf;
     ra.sAll = s_all;
+    const MeanArgs mean_args{cost_sums ? cost_means : nullptr, alph[0], alph[3], alph[4], alph[5]};
     memset(&ra.seg, 0, sizeof(ra.seg));
     if (seg) ra.seg = *seg;                       // (several time segments in one launch: the one-CU kernel only, NOCF_E_SHAPE otherwise)
     ra.act = nullptr; ra.actRows = 0;             // (only the split-role kernel records activations: set below)
@@ -1941,7 +1954,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         g_last_kernel = "rollout_lane_kernel";
         if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
         if (cost_sums) {
-            hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
+            hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp, mean_args);
             e = hipGetLastError();
             if (e) return (int)e;
         }
@@ -1964,7 +1977,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             g_last_errp = errp;
             if (g_prof_on) g_prof_events.emplace_back(ev0, ev1);
             if (cost_sums) {
-                hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
+                hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp, mean_args);
                 e = hipGetLastError();
                 if (e) return (int)e;
             }
@@ -2022,7 +2035,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             e = hipGetLastError();
             if (e) return (int)e;
         } else if (cost_sums) {
-            hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
+            hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp, mean_args);
             e = hipGetLastError();
             if (e) return (int)e;
         }
@@ -2071,7 +2084,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     if (e) return (int)e;
     if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
     if (cost_sums) {
-        hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp);
+        hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp, mean_args);
         e = hipGetLastError();
         if (e) return (int)e;
     }
@@ -2084,6 +2097,15 @@ int nocf_rollout_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, i
                      void* workspace, size_t workspace_bytes, void* stream) {
     return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, zFull, ctrlFull,
                         workspace, workspace_bytes, stream, nullptr);
+}
+
+int nocf_rollout_means_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
+                           double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
+                           float* z_out, float* persample, float* cost_sums, float* cost_means, float* zFull, float* ctrlFull,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (cost_means && !cost_sums) return NOCF_E_NULL;
+    return rollout_impl(phi, prob, x, n, t0, t1, nt, stepper, alph, z_out, persample, cost_sums, zFull, ctrlFull,
+                        workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cost_means);
 }
 
 int nocf_rollout_segments_f32(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,

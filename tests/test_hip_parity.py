@@ -276,7 +276,6 @@ def test_shock_sweep_with_the_shared_prefix_matches_per_shock_time_rollouts_and_
     h = T / int(T nt), equal to every segment's own h to the last bit or two -- and the small case also equals the oracle.  A shock time
     off the shared grid (0.33 at nt = 50: 16 steps of 0.020625) takes the per-time path inside the same sweep."""
     from neuraloc_amd.shock import shock_rollout, shock_sweep, _on_shared_grid
-    from neuraloc_amd import OCflow as _pkg_fn                                        # noqa: F401
     g = load_golden_by_name(name)
     net, prob = make_net(g, DEV), make_prob(g, DEV, training=False)
     d, nt = g.meta["d"], 50 if name != "swarm50" else 20
@@ -289,7 +288,8 @@ def test_shock_sweep_with_the_shared_prefix_matches_per_shock_time_rollouts_and_
     if shocks.shape[0] > 1:
         shocks[1, :] = 0.02
     launches = []
-    import neuraloc_amd.OCflow as ocm
+    import importlib
+    ocm = importlib.import_module("neuraloc_amd.OCflow")       # (the module: the package re-exports the function under the same name)
     real = ocm._launch_segments
     monkeypatch.setattr(ocm, "_launch_segments", lambda *a, **k: (launches.append(len(a[3])), real(*a, **k))[1])
     got = shock_sweep(x, net, prob, nt, times, shocks, alph=g.meta["alph"])
