@@ -224,11 +224,11 @@ def quick_measure(name, dev, steps=10, warmup=3, n_rows=0):
         times = [0.1 * k for k in range(1, 10)]
         shocks = torch.zeros(1, meta["d"], device=dev)
         shocks[0, 0:3] = torch.tensor([0.5, -0.5, 0.25])
-        for _ in range(2):
+        for _ in range(3):
             shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 3
+        reps = 5
         for _ in range(reps):
             shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
         torch.cuda.synchronize()
@@ -456,7 +456,7 @@ def main():
             # config 5 at 8 GPUs, on this one GPU: what a rank's rollout costs when the node is not there to measure it
             for name, rows in (("swarm50", 512), ("swarm50", 256), ("swarm50", 128), ("singlequad", 512)):
                 try:
-                    r = quick_measure(name, dev, steps=20, n_rows=rows)
+                    r = quick_measure(name, dev, steps=50, warmup=10, n_rows=rows)
                     r["proxy_for"] = f"one rank's batch of {name} at {1024 // rows if name == 'swarm50' else 4096 // rows} GPUs (strong scaling)"
                     others.append(r)
                 except Exception as ex:

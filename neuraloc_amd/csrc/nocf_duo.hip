@@ -260,6 +260,7 @@ struct DCtx {
     int udelay;                    // naps (64 clocks each) in front of the FIRST poll for U: see the U gather
     int pw;                        // LDS float index of this wave's words: [3 kinds][4 tiles][2] intervals, then [4 tiles] anchors; -1: no prediction
     unsigned qs, lead;             // sleep quanta (64 clocks) per clock tick, 16.16 fixed point; the lead in ticks
+    int pwsh;                      // the nap ends at anchor + d - (d >> pwsh) - lead
 };
 enum { DPW_S = 0, DPW_G = 1, DPW_V = 2, DPW_ANCHOR = 24, DPW_WORDS = 32 };
 __device__ __forceinline__ unsigned du_clock() { return (unsigned)__builtin_amdgcn_s_memtime(); }
@@ -292,7 +293,7 @@ __device__ __forceinline__ DWait du_wait_begin(DCtx& g, int kind, int t) {
     const unsigned d2 = __builtin_amdgcn_readfirstlane(__float_as_uint(lds[w.at + 1]));
     const unsigned d = w.d1 < d2 ? w.d1 : d2;
     if (w.anchor != 0u && d >= 4u * g.lead) {                  // (shorter intervals are hops: not predictable to a poll's length)
-        const int ahead = (int)(w.anchor + d - (d >> 2) - g.lead - du_clock());        // ticks until the nap should end
+        const int ahead = (int)(w.anchor + d - (d >> g.pwsh) - g.lead - du_clock());   // ticks until the nap should end
         if (ahead > 0 && (unsigned)ahead < d) {
             const unsigned q = (unsigned)(((unsigned long long)(unsigned)ahead * g.qs) >> 16);
             for (unsigned i = 0; i < (q >> 2); ++i) __builtin_amdgcn_s_sleep(4);
@@ -638,6 +639,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     g.fast = 0; g.spin_max = dp.spin_max; g.dead = false; g.slow = NT > 1;
     g.pw = -1; g.qs = 0u; g.lead = 0u;                          // (set per role below: the slots live in that role's LDS carve)
     g.udelay = (dp.dbg >> 8) & 15;
+    g.pwsh = 2 + ((dp.dbg >> 12) & 3);
     const float4* ws4 = reinterpret_cast<const float4*>(ws);
     float4* L4 = reinterpret_cast<float4*>(lds);
     const int vb = lane * 16;                                   // this lane's 16 bytes of a fragment
@@ -1530,7 +1532,8 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
         dp.cb = phi->cb;
         dp.fast = du_env_int("NOCF_DUO_FAST", 1);
         dp.mapmode = du_env_int("NOCF_DUO_MAP", 3);                 // bit 0: A / B of a member adjacent in the static map; bit 1: CU census (see the kernel)
-        dp.dbg = (du_env_int("NOCF_DUO_DBG", 0) & 0xff) | ((du_env_int("NOCF_DUO_UDELAY", dp.NT == 1 ? 0 : 6) & 15) << 8);   // (measured: n = 1024 5.21 -> 5.15 ms with 6, nothing with one tile)
+        dp.dbg = (du_env_int("NOCF_DUO_DBG", 0) & 0xff) | ((du_env_int("NOCF_DUO_UDELAY", dp.NT == 1 ? 0 : 6) & 15) << 8) |
+                 ((du_env_int("NOCF_DUO_PWSH", GM == DU_GMAX ? 1 : 0) & 3) << 12);     // (measured, tools/r5_knobs.sh: fine form 2.35 -> 2.32 / 2.78 -> 2.66 ms at 7/8 of the interval, default form 3.33 -> 3.41; 15/16 oversleeps everywhere)   // (measured: n = 1024 5.21 -> 5.15 ms with 6, nothing with one tile)
         dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
         // (every chunk: the plan record changes with the chunk's rows; the same launch clears the error words / tables and fills the
         // exchange area with the sentinel)
@@ -1600,7 +1603,7 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
         dp.cb = phi->cb;
         dp.fast = du_env_int("NOCF_DUO_FAST", 1);
         dp.mapmode = du_env_int("NOCF_DUO_MAP", 3);
-        dp.dbg = du_env_int("NOCF_DUO_DBG", 0);
+        dp.dbg = (du_env_int("NOCF_DUO_DBG", 0) & 0xff) | ((du_env_int("NOCF_DUO_BWD_UDELAY", 0) & 15) << 8);
         dp.spin_max = du_env_int("NOCF_DUO_SPIN_MAX", 1000000);
         hipLaunchKernelGGL(duo_pack_kernel, dim3(1024), dim3(256), 0, st, dp, P, ws, r0 == 0 ? 1 : 0);
         e = hipGetLastError();
