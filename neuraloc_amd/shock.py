@@ -86,18 +86,22 @@ def shock_sweep(x, Phi, prob, nt, shock_times, shocks, tspan=(0.0, 1.0), alph=No
         kernel writes each pair's shocked trajectory straight behind its copy of the unshocked prefix: `traj` / `ctrl` are views, not cats;
       * the costs of every segment 1 (running integrals from the trajectory's cost columns, terminal terms from one batched Phi / grad Phi
         call at (z(t_s), t_s): src/OCflow.py:58-90) and of every segment 2 are formed for all pairs at once.
-    Shock times off the grid, double precision, row-sharded sweeps (`group`) and networks without a segment-taking kernel run
-    shock_rollout per pair, as before (shared=False forces that)."""
+    Row-sharded sweeps (`group`: x holds this rank's rows): every rank runs ALL (t_s, shock) pairs of its rows this way -- at 512 rows per
+    rank the second-segment launch still has 9 x 32 tiles -- and the cost sums of all first / all second segments are all-reduced as two
+    small tensors (plus one flag: the ranks agree on the path before any of them reduces); trajectories stay sharded by rows.
+    Shock times off the grid, double precision, gather=True and networks without a segment-taking kernel run shock_rollout per pair, as before
+    (shared=False forces that)."""
     alph = list(Phi.alph if alph is None else alph)
     times = [float(t) for t in shock_times]
     K = int(shocks.shape[0])
     T, N, h, on = _on_shared_grid(tspan, nt, times)
-    use = (shared and group is None and x.dtype == torch.float32 and x.is_cuda and len(times) * K >= 2
-           and x.shape[0] % 16 == 0 and any(k is not None for k in on))
+    # (every term of `use` is the same on all ranks of a sharded sweep, except the row count: that one goes through _sweep_shared's flag)
+    use = (shared and not (group is not None and gather) and x.dtype == torch.float32 and len(times) * K >= 2
+           and any(k is not None for k in on))
     fast = {}
     if use:
         fast = _sweep_shared(x, Phi, prob, nt, [(i, t, on[i]) for i, t in enumerate(times) if on[i] is not None], shocks, T, N,
-                             tspan, alph, stepper) or {}
+                             tspan, alph, stepper, group) or {}
     out = []
     for i, t_s in enumerate(times):
         for k in range(K):
@@ -116,18 +120,48 @@ def _means(sums, alph):
     return [(Jc[p], [means[p, j] for j in range(7)]) for p in range(sums.shape[0])]
 
 
-def _sweep_shared(x, Phi, prob, nt, on_grid, shocks, T, N, tspan, alph, stepper):
-    """the shared-prefix sweep of shock_sweep; returns {(time index, shock index): result dict} or None (no segment kernel for this shape)"""
+def _sweep_shared(x, Phi, prob, nt, on_grid, shocks, T, N, tspan, alph, stepper, group=None):
+    """the shared-prefix sweep of shock_sweep; returns {(time index, shock index): result dict} or None (no segment kernel for this shape, or --
+    sharded -- some rank could not take this path: all ranks then return None together)"""
     n, d = x.shape
     K = int(shocks.shape[0])
     shocks = torch.as_tensor(shocks, dtype=x.dtype, device=x.device)
     pairs = [(i, t, ns, k) for (i, t, ns) in on_grid for k in range(K)]
+    grp = None if group is True else group
     with torch.no_grad():
-        # (1) the unshocked trajectory, once
-        _, _, zF, cF = _oc._launch(x, Phi, prob, [tspan[0], T], N, stepper, alph, True)           # [N+1, n, d+4], [N+1, n, a]
-        cdim = cF.shape[2]
+        ok = n % 16 == 0
+        raw = []
+        if ok:
+            # (1) the unshocked trajectory, once
+            _, _, zF, cF = _oc._launch(x, Phi, prob, [tspan[0], T], N, stepper, alph, True)           # [N+1, n, d+4], [N+1, n, a]
+            cdim = cF.shape[2]
+            # (2) all second segments: MAX_SEGMENTS pairs per launch
+            for c0 in range(0, len(pairs), _oc.MAX_SEGMENTS):
+                chunk = pairs[c0:c0 + _oc.MAX_SEGMENTS]
+                P = len(chunk)
+                xs = torch.stack([zF[ns, :, :d] + shocks[k:k + 1] for (_, _, ns, k) in chunk]).reshape(P * n, d).contiguous()
+                Z = torch.empty(nt + 3, P * n, d + 4, dtype=x.dtype, device=x.device)
+                Cc = torch.empty(nt + 3, P * n, cdim, dtype=x.dtype, device=x.device)
+                # every pair's copy of the unshocked prefix (slots beyond its nShock are overwritten by its second segment)
+                Z[:N + 1].view(N + 1, P, n, d + 4).copy_(zF.unsqueeze(1).expand(N + 1, P, n, d + 4))
+                Cc[:N + 1].view(N + 1, P, n, cdim).copy_(cF.unsqueeze(1).expand(N + 1, P, n, cdim))
+                got = _oc._launch_segments(xs, Phi, prob, [t for (_, t, _, _) in chunk], tspan[1], [1 + nt - ns for (_, _, ns, _) in chunk], n,
+                                           stepper, alph, slot0s=[ns + 1 for (_, _, ns, _) in chunk], zFull=Z, ctrlFull=Cc)
+                if got is None:
+                    ok = False
+                    break
+                raw.append((chunk, xs, Z, Cc, got[1]))
+        if group is not None:                               # the ranks take this path together or not at all (before anybody reduces anything)
+            import torch.distributed as dist
+            from .distributed import reduce_cost_sums
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(grp) > 1:
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=x.device if dist.get_backend(grp) != "gloo" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=grp)
+                ok = bool(int(flag[0]))
+        if not ok:
+            return None
         res = {}
-        # costs of every segment 1: running integrals at its end + the terminal terms at (z(t_s), t_s)
+        # costs of every segment 1: running integrals at its end + the terminal terms at (z(t_s), t_s)  (src/OCflow.py:58-90)
         ends = torch.stack([zF[ns] for (_, _, ns) in on_grid])                                   # [S, n, d+4]
         S = ends.shape[0]
         tcol = torch.tensor([t for (_, t, _) in on_grid], dtype=x.dtype, device=x.device).view(S, 1, 1).expand(S, n, 1)
@@ -140,26 +174,16 @@ def _sweep_shared(x, Phi, prob, nt, on_grid, shocks, T, N, tspan, alph, stepper)
         sums1 = torch.stack((ends[:, :, d].sum(1), cG.sum(1), ends[:, :, d + 1].sum(1), (phi1 - a0 * cG).abs().sum(1),
                              (g1[:, :, :d] - a0 * resid).abs().sum(dim=(1, 2)), ends[:, :, d + 2].sum(1), ends[:, :, d + 3].sum(1),
                              torch.full((S,), float(n), dtype=x.dtype, device=x.device)), dim=1)  # [S, 8]
-        costs1 = _means(sums1, alph)
-        # (2) all second segments: MAX_SEGMENTS pairs per launch
-        for c0 in range(0, len(pairs), _oc.MAX_SEGMENTS):
-            chunk = pairs[c0:c0 + _oc.MAX_SEGMENTS]
-            P = len(chunk)
-            xs = torch.stack([zF[ns, :, :d] + shocks[k:k + 1] for (_, _, ns, k) in chunk]).reshape(P * n, d).contiguous()
-            Z = torch.empty(nt + 3, P * n, d + 4, dtype=x.dtype, device=x.device)
-            Cc = torch.empty(nt + 3, P * n, cdim, dtype=x.dtype, device=x.device)
-            # every pair's copy of the unshocked prefix (slots beyond its nShock are overwritten by its second segment)
-            Z[:N + 1].view(N + 1, P, n, d + 4).copy_(zF.unsqueeze(1).expand(N + 1, P, n, d + 4))
-            Cc[:N + 1].view(N + 1, P, n, cdim).copy_(cF.unsqueeze(1).expand(N + 1, P, n, cdim))
-            got = _oc._launch_segments(xs, Phi, prob, [t for (_, t, _, _) in chunk], tspan[1], [1 + nt - ns for (_, _, ns, _) in chunk], n,
-                                       stepper, alph, slot0s=[ns + 1 for (_, _, ns, _) in chunk], zFull=Z, ctrlFull=Cc)
-            if got is None:
-                return None
-            _, sums2, _, _ = got
-            costs2 = _means(sums2, alph)
-            si = {i: j for j, (i, _, _) in enumerate(on_grid)}
+        sums2 = torch.cat([r[4] for r in raw], dim=0)                                             # [pairs, 8]
+        if group is not None:
+            sums1, sums2 = reduce_cost_sums(sums1.contiguous(), grp), reduce_cost_sums(sums2.contiguous(), grp)
+        costs1, costs2 = _means(sums1, alph), _means(sums2, alph)
+        si = {i: j for j, (i, _, _) in enumerate(on_grid)}
+        p0 = 0
+        for chunk, xs, Z, Cc, _ in raw:
             for p, (i, t, ns, k) in enumerate(chunk):
                 res[(i, k)] = {"traj": Z[:, p * n:(p + 1) * n, :d].permute(1, 2, 0), "ctrl": Cc[:, p * n:(p + 1) * n, :].permute(1, 2, 0),
-                               "costs1": costs1[si[i]], "costs2": costs2[p], "nShock": ns, "x_shocked": xs[p * n:(p + 1) * n]}
+                               "costs1": costs1[si[i]], "costs2": costs2[p0 + p], "nShock": ns, "x_shocked": xs[p * n:(p + 1) * n]}
+            p0 += len(chunk)
         _lib.check_errors(sync=True)        # results that are consumed on the host (plots, files): a failed launch must raise here
     return res

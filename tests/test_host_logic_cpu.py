@@ -142,3 +142,19 @@ def test_contract_splits_the_rows_of_wide_products_and_keeps_the_sum():
         acc = _contract(X, Y, got.clone())
         assert float((acc.double() - 2 * want).abs().max()) <= 4e-5 * (K ** 0.5)
         assert torch.equal(_contract(X, Y), got)                       # run-to-run identical
+
+
+def test_shock_times_on_the_shared_step_grid():
+    """neuraloc_amd.shock._on_shared_grid: which first segments (int(t_s nt) steps of t_s / int(t_s nt): src/plotter.py:815-818) are prefixes of
+    ONE unshocked rollout to the largest shock time"""
+    from neuraloc_amd.shock import _on_shared_grid
+    times = [0.1 * k for k in range(1, 10)]                      # 0.30000000000000004 etc.: the values a sweep script makes
+    T, N, h, on = _on_shared_grid((0.0, 1.0), 50, times)
+    assert (N, on) == (45, [5, 10, 15, 20, 25, 30, 35, 40, 45]) and abs(T - 0.9) < 1e-15 and abs(h - 0.02) < 1e-15
+    T, N, h, on = _on_shared_grid((0.0, 1.0), 50, [0.1, 0.33, 0.5, 0.999])
+    assert on == [None, None, None, 49] or on[1] is None          # 0.33: 16 steps of 0.020625 -- not on the grid of the largest time
+    T, N, h, on = _on_shared_grid((0.0, 1.0), 50, [0.2, 0.33, 0.5])
+    assert (N, on) == (25, [10, None, 25])
+    T, N, h, on = _on_shared_grid((0.0, 1.0), 20, [0.01, 0.5])   # int(0.01 * 20) = 0: no segment 1 at all (shock_rollout raises for it)
+    assert on == [None, 10]
+    assert _on_shared_grid((0.0, 1.0), 20, [0.01])[3] == [None]

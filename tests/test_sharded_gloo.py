@@ -182,3 +182,114 @@ def test_two_rank_sharded_shock_sweep_matches_single_rank(tmp_path):
         assert abs(float(r["J2"]) - float(want["costs2"][0])) <= 1e-5 * abs(float(want["costs2"][0]))
         assert np.allclose(r["zF"], zW.numpy(), rtol=1e-4, atol=1e-4) and np.allclose(r["cF"], cW.numpy(), rtol=1e-4, atol=1e-4)
     assert (int(r0["loc_rows"]), int(r1["loc_rows"])) == (5, 4)
+
+
+def _checker_segments(orc, P, S):
+    """a stand-in for neuraloc_amd.OCflow._launch_segments (several time segments in one launch), computed by the oracle segment by segment"""
+    def launch(x, Phi, prob, t0s, t1, nts, rows, stepper, alph, slot0s=None, zFull=None, ctrlFull=None):
+        n = x.shape[0]
+        slot0s = [0] * len(t0s) if slot0s is None else slot0s
+        sums = torch.zeros(len(t0s), 8)
+        with torch.no_grad():
+            for k, (t0, ntk, s0) in enumerate(zip(t0s, nts, slot0s)):
+                xs = x[k * rows:min(n, (k + 1) * rows)]
+                tab = orc.persample_table(xs, P, S, [t0, t1], ntk, stepper, alph)
+                sums[k] = torch.cat((tab.double().sum(0), torch.tensor([float(xs.shape[0])], dtype=torch.float64))).float()
+                z, c = orc.rollout(xs, P, S, [t0, t1], ntk, stepper, alph, intermediates=True)
+                zFull[s0:s0 + ntk + 1, k * rows:k * rows + xs.shape[0]] = z.permute(2, 0, 1)
+                ctrlFull[s0:s0 + ntk + 1, k * rows:k * rows + xs.shape[0]] = c.permute(2, 0, 1)
+        return None, sums, zFull, ctrlFull
+    return launch
+
+
+def _sweep_objects(orc, P, S, m, xtarget):
+    class _Net:                                          # what the shared-prefix sweep asks of the network object
+        alph = m["alph"]
+        _value_f32 = staticmethod(lambda s: orc.phi_value(P, s))
+        _grad_f32 = staticmethod(lambda s: orc.phi_grad(P, s))
+
+    class _Prob:
+        pass
+    _Prob.xtarget = xtarget
+    return _Net, _Prob
+
+
+def _sweep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_golden
+    from util_hip import make_oracle
+    from oracle import ocflow_oracle as orc
+    import importlib
+    ocmod = importlib.import_module("neuraloc_amd.OCflow")
+    from neuraloc_amd.distributed import shard_rows
+    from neuraloc_amd.shock import shock_sweep
+    g = load_golden("softcorridor")
+    P, S = make_oracle(g, training=False)
+    m = g.meta
+    ocmod._launch = _checker_launch(orc, P, S)
+    calls = []
+    seg = _checker_segments(orc, P, S)
+    ocmod._launch_segments = lambda *a, **k: (calls.append(len(a[3])), seg(*a, **k))[1]
+    _Net, _Prob = _sweep_objects(orc, P, S, m, g.t("xtarget"))
+    x = g.t("x")[:32]                                    # two shards of 16 rows: whole tiles, the shared-prefix path
+    lo, hi = shard_rows(x.shape[0], rank, world)
+    shocks = torch.tensor([[-0.2, -0.7, -0.0, -0.6], [0.1, 0.0, 0.0, 0.2]])
+    res = shock_sweep(x[lo:hi], _Net, _Prob, 10, [0.2, 0.5, 0.33], shocks, alph=m["alph"], group=True)
+    assert calls == [4], calls                           # the four on-grid pairs in ONE segment launch; t_s = 0.33 took the per-pair path
+    np.savez(os.path.join(out_dir, f"sweep{rank}.npz"), n=len(res),
+             **{f"traj{i}": r["traj"].numpy() for i, r in enumerate(res)},
+             **{f"J1_{i}": float(r["costs1"][0]) for i, r in enumerate(res)}, **{f"J2_{i}": float(r["costs2"][0]) for i, r in enumerate(res)})
+    # a rank whose shard is not whole tiles makes EVERY rank take the per-pair path (the flag all-reduce): no hang, same answers
+    x2 = g.t("x")[:24]
+    lo2, hi2 = (0, 16) if rank == 0 else (16, 24)
+    calls.clear()
+    res2 = shock_sweep(x2[lo2:hi2], _Net, _Prob, 10, [0.2, 0.5], shocks[:1], alph=m["alph"], group=True)
+    np.savez(os.path.join(out_dir, f"sweepb{rank}.npz"), J2=float(res2[1]["costs2"][0]), ncalls=len(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_shock_sweep_with_the_shared_prefix(tmp_path):
+    """BASELINE config 5 over a row-sharded batch: every rank runs all (t_s, shock) pairs of its rows with the shared unshocked prefix and ONE
+    segment launch; the costs are global means (two small all-reduces + the agreement flag), trajectories stay sharded -- equal to the
+    single-process per-pair result; a rank that cannot take the path takes every rank off it."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from conftest import load_golden
+    from util_hip import make_oracle
+    from oracle import ocflow_oracle as orc
+    import importlib
+    ocmod = importlib.import_module("neuraloc_amd.OCflow")
+    from neuraloc_amd.shock import shock_rollout
+    world = 2
+    mp.spawn(_sweep_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden("softcorridor")
+    P, S = make_oracle(g, training=False)
+    m = g.meta
+    saved = ocmod._launch
+    try:
+        ocmod._launch = _checker_launch(orc, P, S)
+        _Net, _Prob = _sweep_objects(orc, P, S, m, g.t("xtarget"))
+        x = g.t("x")[:32]
+        shocks = torch.tensor([[-0.2, -0.7, -0.0, -0.6], [0.1, 0.0, 0.0, 0.2]])
+        want = [shock_rollout(x, _Net, _Prob, 10, t, shocks[k:k + 1], alph=m["alph"]) for t in (0.2, 0.5, 0.33) for k in range(2)]
+        want_b = shock_rollout(g.t("x")[:24], _Net, _Prob, 10, 0.5, shocks[:1], alph=m["alph"])
+    finally:
+        ocmod._launch = saved
+    r = [np.load(tmp_path / "sweep0.npz"), np.load(tmp_path / "sweep1.npz")]
+    assert int(r[0]["n"]) == int(r[1]["n"]) == 6
+    for i, w in enumerate(want):
+        both = np.concatenate([r[0][f"traj{i}"], r[1][f"traj{i}"]], axis=0)      # the ranks' row shards, in rank order
+        assert both.shape == tuple(w["traj"].shape)
+        assert np.allclose(both, w["traj"].numpy(), rtol=1e-5, atol=1e-4), i
+        for rr in r:
+            assert abs(float(rr[f"J1_{i}"]) - float(w["costs1"][0])) <= 2e-5 * abs(float(w["costs1"][0])), i
+            assert abs(float(rr[f"J2_{i}"]) - float(w["costs2"][0])) <= 2e-5 * abs(float(w["costs2"][0])), i
+    for k in range(2):
+        b = np.load(tmp_path / f"sweepb{k}.npz")
+        # (rank 0's shard qualified: it had launched before the flag took both ranks to the per-pair path; rank 1 never launched segments)
+        assert int(b["ncalls"]) == (1 if k == 0 else 0) and abs(float(b["J2"]) - float(want_b["costs2"][0])) <= 2e-5 * abs(float(want_b["costs2"][0]))

@@ -118,3 +118,60 @@ def test_two_rank_sharded_shock_sweep_on_the_gpu(tmp_path):
         assert np.array_equal(r["zF"], zW.cpu().numpy()) and np.array_equal(r["cF"], cW.cpu().numpy())
         for k, w in (("J1", want["costs1"][0]), ("J2", want["costs2"][0])):
             assert abs(float(r[k]) - float(w)) <= 1e-5 * abs(float(w))
+
+
+def _sweep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import neuraloc_amd as na
+    from neuraloc_amd import _lib
+    from neuraloc_amd.shock import shock_sweep
+    from conftest import load_golden
+    from util_hip import full_states, make_net, make_prob
+    dev = torch.device("cuda:0")
+    g = load_golden("singlequad")
+    net, prob = make_net(g, dev), make_prob(g, dev, training=False)
+    x = full_states(g, 5)[:64].to(dev)                     # 64 rows over 2 ranks: two whole tiles each -> the shared-prefix path
+    lo, hi = na.shard_rows(x.shape[0], rank, world)
+    shocks = torch.zeros(1, g.meta["d"], device=dev)
+    shocks[0, :3] = torch.tensor([0.5, -0.5, 0.25])
+    times = [0.1 * k for k in range(1, 10)]
+    with torch.no_grad():
+        res = shock_sweep(x[lo:hi].contiguous(), net, prob, 50, times, shocks, alph=g.meta["alph"], group=True)
+    np.savez(os.path.join(out_dir, f"w{rank}.npz"), kernel=_lib.lib().nocf_last_rollout_kernel().decode(),
+             **{f"traj{i}": r["traj"].cpu().numpy() for i, r in enumerate(res)},
+             **{f"J1_{i}": float(r["costs1"][0]) for i, r in enumerate(res)}, **{f"J2_{i}": float(r["costs2"][0]) for i, r in enumerate(res)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_shock_sweep_with_the_shared_prefix_on_the_gpu(tmp_path):
+    """BASELINE config 5 sharded by rows: every rank runs all nine shock times of its rows with the shared unshocked prefix and one
+    segment launch (nocf_rollout_segments_f32), the costs are global means: equal to the single-process sweep (trajectories row for row: the
+    per-sample arithmetic does not depend on the sharding) and, through it, to the per-t_s rollouts (tests/test_hip_parity.py)"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import neuraloc_amd as na
+    from neuraloc_amd.shock import shock_sweep
+    from conftest import load_golden
+    from util_hip import full_states, make_net, make_prob
+    world = 2
+    mp.spawn(_sweep_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    g = load_golden("singlequad")
+    net, prob = make_net(g, dev), make_prob(g, dev, training=False)
+    x = full_states(g, 5)[:64].to(dev)
+    shocks = torch.zeros(1, g.meta["d"], device=dev)
+    shocks[0, :3] = torch.tensor([0.5, -0.5, 0.25])
+    with torch.no_grad():
+        want = shock_sweep(x, net, prob, 50, [0.1 * k for k in range(1, 10)], shocks, alph=g.meta["alph"])
+    r = [np.load(tmp_path / "w0.npz"), np.load(tmp_path / "w1.npz")]
+    assert str(r[0]["kernel"]) == "rollout_mono_kernel"
+    for i, w in enumerate(want):
+        both = np.concatenate([r[0][f"traj{i}"], r[1][f"traj{i}"]], axis=0)
+        assert np.array_equal(both, w["traj"].cpu().numpy()), f"pair {i}: trajectories depend on the sharding"
+        for rr in r:
+            assert abs(float(rr[f"J1_{i}"]) - float(w["costs1"][0])) <= 1e-5 * abs(float(w["costs1"][0]))
+            assert abs(float(rr[f"J2_{i}"]) - float(w["costs2"][0])) <= 1e-5 * abs(float(w["costs2"][0]))
