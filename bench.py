@@ -183,32 +183,51 @@ def read_traffic(workload, kernel, n_local):
     return j.get("hbm_bytes_per_launch"), f"{os.path.relpath(tp, REPO)} ({j.get('source', '?')}, {j.get('collected', '?')})"
 
 
-def bench_shock(args, dev):
-    """BASELINE config 5: singlequad, 9 shock times x 4096 states x nt = 50, trajectories and controls kept"""
+def bench_shock(args, dev, world=1, rank=0, dist=None):
+    """BASELINE config 5: singlequad, 9 shock times x 4096 states x nt = 50, trajectories and controls kept.  N GPUs: the states are sharded by
+    rows (strong scaling of the global batch), every rank runs all shock times of its rows (shock_sweep(group=True): shared unshocked prefix,
+    one segment launch), the costs are global means; trajectories stay sharded."""
     from neuraloc_amd.shock import shock_sweep
     meta, sd, xtarget, xInit = load_workload("singlequad")
     net, prob = build_objects(meta, sd, xtarget, dev)
     n = args.n or meta["n_full"]
     nt = args.nt or meta["nt"]
-    x = make_states(meta, xInit, n, seed=200).to(dev)
+    lo, hi = shard_rows(n, rank, world)
+    x = make_states(meta, xInit, n, seed=200)[lo:hi].contiguous().to(dev)
     times = [0.1 * k for k in range(1, 10)]
     shocks = torch.zeros(1, meta["d"], device=dev)
     shocks[0, 0:3] = torch.tensor([0.5, -0.5, 0.25])
+    kw = {"group": True} if world > 1 else {}
     for _ in range(max(1, args.warmup)):
-        shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
+        shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"], **kw)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"])
+        res = shock_sweep(x, net, prob, nt, times, shocks, alph=meta["alph"], **kw)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    out = {"metric": "shocked trajectories/sec (two-segment rollouts with trajectories and controls kept)",
-           "value": len(times) * n * args.steps / el, "unit": "trajectories/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-           "data": "synthetic states; pretrained reference weights exported to npz",
-           "config": {"workload": f"singlequad-shock d={meta['d']} m={meta['m']} nt={nt} n={n} x {len(times)} shock times, rk4, eval-mode, fp32, "
-                                  "intermediates=True (zFull + ctrlFull written)", "Jc_last_segment": float(res[-1]["costs2"][0])}}
-    print(json.dumps(out), flush=True)
+    if dist:
+        host_reduce = os.environ.get("NOCF_BENCH_BACKEND", "nccl") != "nccl"
+        tt = torch.tensor([el], dtype=torch.float64, device="cpu" if host_reduce else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    if rank == 0:
+        out = {"metric": "shocked trajectories/sec (two-segment rollouts with trajectories and controls kept)",
+               "value": len(times) * n * args.steps / el, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic states; pretrained reference weights exported to npz",
+               "config": {"workload": f"singlequad-shock d={meta['d']} m={meta['m']} nt={nt} n={n} x {len(times)} shock times, rk4, eval-mode, fp32, "
+                                      "intermediates=True (zFull + ctrlFull written)", "rows_per_gpu": hi - lo,
+                          "Jc_last_segment": float(res[-1]["costs2"][0])}}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
 
 
 def quick_measure(name, dev, steps=10, warmup=3, n_rows=0):
@@ -367,8 +386,7 @@ def main():
     torch.cuda.set_device(dev)
 
     if args.workload == "singlequad-shock":
-        assert world == 1, "the shock sweep is benchmarked on one GPU"
-        return bench_shock(args, dev)
+        return bench_shock(args, dev, world, rank, dist)
 
     meta, sd, xtarget, xInit = load_workload(args.workload)
     n_arg = args.n or meta["n_full"]

@@ -107,3 +107,22 @@ def test_bench_starts_its_own_ranks():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"].startswith("gloo") and line["value"] > 0
     assert line["config"]["rows_per_gpu"] == 512 and line["scaling"] == "strong"
+
+
+def test_bench_shock_sweep_over_two_ranks():
+    """BASELINE config 5 with `--gpus 2` (self-launched; the ranks share the test box's one GPU, so gloo): rows sharded, every rank runs all nine
+    shock times of its 2048 rows on the shared-prefix path (the one-CU kernel needs no co-residency, so two ranks on one GPU are fine), one line"""
+    import json
+    env = dict(os.environ)
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), "NOCF_BENCH_BACKEND": "gloo"})
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", "singlequad-shock", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["rows_per_gpu"] == 2048 and line["value"] > 0
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "singlequad-shock", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = line["config"]["Jc_last_segment"], ref["config"]["Jc_last_segment"]
+    assert abs(a - b) <= 1e-5 * abs(b), (a, b)            # global means: the sharded sweep's costs are the full batch's
