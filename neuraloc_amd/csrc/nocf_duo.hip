@@ -1,4 +1,4 @@
-// nocf_duo.hip -- weight-STATIONARY rollout for wide networks (m = 512, nTh = 2, point-agent problems), round 3:
+// nocf_duo.hip -- weight-STATIONARY rollout for wide networks (m = 512 or 256, nTh = 2, point-agent problems), rounds 3-5:
 // two ROLE workgroups per CU, two instruction streams per SIMD.
 //
 // Why.  Round 2's slab kernel kept a member's slice of K1 in registers in BOTH orientations (2 x 128 per lane), which
@@ -47,6 +47,11 @@
 // A group whose 16 workgroups report the same XCC id keeps payloads in that XCD's L2 (plain stores); any other group
 // writes through (sc1).  Placement-independent; workgroups of a group share blockIdx % 8, and the CU census at kernel start makes
 // the two workgroups of a CU role A and role B of the SAME member (speed only).
+//
+// Round 5: the kernel is a template over the group geometry and the width (DuoCfg<G, KBM> below): 8 members of 64 hidden units as described
+// here (the default, and the adjoint's), 16 members of 32 with the contraction of P1 / P2 / P3 split over wave pairs for batches of up to 16
+// tiles (the 4- and 8-GPU shards of n_train = 1024: it uses the CUs the default form leaves idle), and 4 members of 64 for 256-wide networks.
+// Waiting waves sleep through most of a long, periodic wait instead of polling (DCtx: predictive waiting, one-tile groups).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
