@@ -556,14 +556,16 @@ struct DuoRun { long row0, n_total; };             // rows of this launch inside
 
 // REC: the training variant also stores every stage input (RollArgs::sAll); ZF: intermediates (trajectories and controls, one more
 // evaluation per step); the plain evaluation variant carries no trace of either
-template <int PD, bool REC, bool ZF, int GM = DU_G, int KBMT = DU_KBM>
+// ONE: the launch has one tile per group in the default geometry (257 ... 512 rows): the instantiation WITH the owner's flag below.  The flag
+// costs that geometry registers it does not have (11 spilled instead of 2-5: n = 1024 +2 %), and only one-tile groups gain from it
+template <int PD, bool REC, bool ZF, int GM = DU_G, int KBMT = DU_KBM, bool ONE = false>
 __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __restrict__ dpp, DevProb pb, float* ws, RollArgs ra, DuoRun rr) {
     typedef DuoCfg<GM, KBMT> CF;
     constexpr int G = CF::G, MTM = CF::MTM, KS = CF::KS, SPM = CF::SPM, KBW = CF::KBW, KB1 = CF::KB1, WPG = CF::WPG, HPM = CF::HPM;
     constexpr int KBM = CF::KBM, MW = CF::M;
     // LDS of the fine form: the waves' partial sums [4 waves][64 lanes][4] (role A: in front of the per-sample blocks; role B: in the half of
     // the K4 region that its half-sized image leaves free)
-    constexpr int DAPX = DA_T, DAPW = DA_T + (KS > 1 ? 1024 : 0), DAT = DAPW + 4 * DPW_WORDS, DBPX = DB_K4 + DU_KBD * MTM * 256, DBPW = DB_END;
+    constexpr int DAPX = DA_T, DAPW = DA_T + (KS > 1 ? 1024 : 0), DAFL = DAPW + 28, DAT = DAPW + 4 * DPW_WORDS, DBPX = DB_K4 + DU_KBD * MTM * 256, DBPW = DB_END;
     static_assert(KS == 1 || DBPX + 1024 <= DB_VEC, "role B's partial sums must fit behind the K4 image");
     const DuoPlan& dp = *dpp;
     const int bid = blockIdx.x;
@@ -631,7 +633,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     const int lane = tid & 63, slot = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ft = KS > 1 ? wave % MTM : wave, kh = KS > 1 ? wave / MTM : 0;                 // this wave's feature tile of the member, its part of the contraction
-    int NT = dp.NT; DU_PIN(NT);
+    int NT = dp.NT; DU_PIN(NT);                                 // (ONE: still read at run time -- as a compile-time 1 the kernel came out with 31 spilled registers instead of 11)
+    constexpr bool FLAGS = ONE || GM != DU_G;                   // the local owner's "about to publish" flag for the stage-state gatherers (see own_state)
     const int d = dp.d;
     const float hN = dp.hN;
     DXOff xo;
@@ -776,6 +779,10 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 qa = v2[0]; qb = v2[1];
             }
             const f32x4 gs = gather_g(s, parG, true, pv);
+            // (round 5) "the stage state of this tile is about to be published": the workgroup's waves that gather it start polling NOW -- one
+            // owner's step and one store + landing later the payload is there, so a poll is in flight when it lands (the shortest hop there
+            // is) but none was during the thousands of cycles before (which the co-resident role's stores paid for in the CU's memory queue)
+            if (FLAGS && lane == 0) __hip_atomic_store(reinterpret_cast<int*>(lds) + DAFL + t, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             DTL(40 * t + 1);
             float q0 = 0.f;
 #pragma unroll
@@ -984,9 +991,19 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // behind a store is not answered before the store has been acknowledged -- vmcnt retires in order -- which occasionally
                     // takes thousands of cycles that every member of the group then waits for: 5.54 -> 5.29 ms)
                     if (e > 1) {
-                        if (SPM == 2) { if (sown < 0) du_gather2<DU_KBD>(g, (wave ^ (wave >> 1)) & 1, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t); }
-                        else if (SPM == 4) du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t);      // (every wave is an owner)
-                        else { const int wh = ((wave - (t & 3)) & 3) - 1; if (wh >= 0 && wh < 2) du_gather2<DU_KBD>(g, wh, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S, DPW_S, t); }
+                        // the waves that own nothing of this tile wait for the local owner's flag (LDS: no request leaves the CU), then gather
+                        auto wait_owner = [&]() {
+                            // (one tile per group only -- measured, tools/r5_ab.sh: 512 rows 3.34 -> 3.16 ms, 128 rows 2.32 -> 2.30; with two tiles
+                            // per group the early polls are worth more than they cost: 1024 rows 5.14 -> 5.29 with the flag)
+                            if (!FLAGS || g.slow) return;
+                            int spins = 0;                  // (one tile per group: du_spin naps 64 clocks; bounded like every wait of this kernel)
+                            while (__hip_atomic_load(reinterpret_cast<int*>(lds) + DAFL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != e) {
+                                if (du_spin(g, spins, DUK_S)) break;
+                            }
+                        };
+                        if (SPM == 2) { if (sown < 0) { wait_owner(); du_gather2<DU_KBD>(g, (wave ^ (wave >> 1)) & 1, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S); } }
+                        else if (SPM == 4) du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);      // (every wave is an owner)
+                        else { const int wh = ((wave - (t & 3)) & 3) - 1; if (wh >= 0 && wh < 2) { wait_owner(); du_gather2<DU_KBD>(g, wh, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S); } }
                     } else du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
                     __syncthreads();
                     DTL(40 * t + 5);
@@ -1479,12 +1496,12 @@ int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size
     return 0;
 }
 
-template <int PD, bool REC, bool ZF, int GM, int KBMT = DU_KBM>
-static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF, GM, KBMT>); }
-template <int GM>
+template <int PD, bool REC, bool ZF, int GM, int KBMT = DU_KBM, bool ONE = false>
+static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF, GM, KBMT, ONE>); }
+template <int GM, bool ONE = false>
 static const void* duo_pick(bool c2, bool rec, bool zf) {
-    return c2 ? (rec ? duo_fn<2, true, false, GM>() : (zf ? duo_fn<2, false, true, GM>() : duo_fn<2, false, false, GM>()))
-              : (rec ? duo_fn<3, true, false, GM>() : (zf ? duo_fn<3, false, true, GM>() : duo_fn<3, false, false, GM>()));
+    return c2 ? (rec ? duo_fn<2, true, false, GM, DU_KBM, ONE>() : (zf ? duo_fn<2, false, true, GM, DU_KBM, ONE>() : duo_fn<2, false, false, GM, DU_KBM, ONE>()))
+              : (rec ? duo_fn<3, true, false, GM, DU_KBM, ONE>() : (zf ? duo_fn<3, false, true, GM, DU_KBM, ONE>() : duo_fn<3, false, false, GM, DU_KBM, ONE>()));
 }
 
 // Which form for a launch of n rows?  NOCF_DUO_G = 8 / 16 forces one; otherwise the fine form where the batch has at most 16 tiles, i.e.
@@ -1511,8 +1528,11 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
     const bool c2 = pb.kind == NOCF_PROB_CROSS2D;
     const bool rec = ra_in.sAll != nullptr;
     const bool zf = ra_in.zFull != nullptr;
+    // (the ONE instantiation: one launch of 32 one-tile groups in the default geometry, i.e. every CU holds the two roles of one member -- the
+    // case the flag is for; measured, tools/r5_ab.sh: 512 rows 3.33 -> 3.13 ms, but 300 / 384 rows (19 / 24 groups, no census pairing) 3.40 -> 3.49)
+    const bool one = GM == DU_G && dp0.NT == 1 && dp0.ngroups == 32 && ra_in.n <= chunk;
     const void* fk = narrow ? (c2 ? duo_fn<2, false, false, 4, 16>() : duo_fn<3, false, false, 4, 16>())
-                            : (GM == DU_G ? duo_pick<DU_G>(c2, rec, zf) : duo_pick<DU_GMAX>(c2, rec, zf));
+                            : (GM == DU_G ? (one ? duo_pick<DU_G, true>(c2, rec, zf) : duo_pick<DU_G>(c2, rec, zf)) : duo_pick<DU_GMAX>(c2, rec, zf));
     const int wpg = 2 * GM;
     // residency: all 16 x ngroups workgroups spin on each other, so every one of them must be resident at once: two per CU
     // (256 registers per lane, <= 80 KB LDS).  The grid is checked against what the runtime says fits; the stream must be
