@@ -104,7 +104,8 @@ enum { DUK_S = 1, DUK_U = 2, DUK_T = 3, DUK_V = 4, DUK_G = 5, DUK_Q = 6, DUK_P =
 // chain that the two roles' tiles interleave on.  An own sample belongs to one member: SPM = 16 / G per member and tile.
 // Width (round 5): KBM = m / 16.  m = 512 (KBM = 32) runs with 8 or 16 members; m = 256 (KBM = 16) with FOUR members of 64 hidden units --
 // the default form's member (one feature tile and the whole contraction per wave, 64 AccVGPRs of resident weights instead of 128), 8 workgroups
-// per tile, four own samples per member and tile (every wave owns one).  Evaluation only for now (training of such networks: the per-tile kernels).
+// per tile, four own samples per member and tile (every wave owns one).  Evaluation, intermediates and the recording forward with the activation
+// record; the adjoint of such networks is the per-tile one (it loads the record).
 template <int G_, int KBM_ = DU_KBM> struct DuoCfg {
     static constexpr int G = G_;
     static constexpr int KBM = KBM_;                // 16-wide k-blocks of the hidden width
@@ -1517,8 +1518,8 @@ static int duo_pick_G(long n) {
 int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, float* ws, size_t ws_bytes, hipStream_t st,
                const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
     if (pb.kind == NOCF_PROB_QUADCOPTER || (ra_in.zFull && ra_in.sAll)) return 1;
-    const bool narrow = phi->m == 256;                             // four members per group, evaluation only (DuoCfg)
-    if (narrow && (ra_in.sAll || ra_in.zFull)) return 1;
+    const bool narrow = phi->m == 256;                             // four members per group (DuoCfg): evaluation, intermediates, the recording forward
+    if (narrow && ra_in.tapeSc) return 1;                          // (no tape: the split-role ADJOINT exists for m = 512 only)
     const int GM = narrow ? 4 : duo_pick_G(ra_in.n);
     // (512 workgroups per launch: 32 groups of 16, 16 of 32, 64 of 8; up to four tiles per group, two with four own samples per member)
     const long chunk = narrow ? duo_rows_per_launch() : duo_rows_per_launch() * DU_G / GM;
@@ -1531,7 +1532,8 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
     // (the ONE instantiation: one launch of 32 one-tile groups in the default geometry, i.e. every CU holds the two roles of one member -- the
     // case the flag is for; measured, tools/r5_ab.sh: 512 rows 3.33 -> 3.13 ms, but 300 / 384 rows (19 / 24 groups, no census pairing) 3.40 -> 3.49)
     const bool one = GM == DU_G && dp0.NT == 1 && dp0.ngroups == 32 && ra_in.n <= chunk;
-    const void* fk = narrow ? (c2 ? duo_fn<2, false, false, 4, 16>() : duo_fn<3, false, false, 4, 16>())
+    const void* fk = narrow ? (c2 ? (rec ? duo_fn<2, true, false, 4, 16>() : (zf ? duo_fn<2, false, true, 4, 16>() : duo_fn<2, false, false, 4, 16>()))
+                                  : (rec ? duo_fn<3, true, false, 4, 16>() : (zf ? duo_fn<3, false, true, 4, 16>() : duo_fn<3, false, false, 4, 16>())))
                             : (GM == DU_G ? (one ? duo_pick<DU_G, true>(c2, rec, zf) : duo_pick<DU_G>(c2, rec, zf)) : duo_pick<DU_GMAX>(c2, rec, zf));
     const int wpg = 2 * GM;
     // residency: all 16 x ngroups workgroups spin on each other, so every one of them must be resident at once: two per CU

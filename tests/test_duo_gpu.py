@@ -210,6 +210,24 @@ def test_duo_256_wide_swarm_network_matches_tile_kernel_and_oracle(n, monkeypatc
     if n <= 100:
         want = orc.persample_table(x, orc.PhiParams.from_state_dict(sd), make_oracle(g, False)[1], [0.0, 1.0], nt, "rk4", m["alph"])
         assert _flips(duo, want) <= 2
+    # ... intermediates (one more evaluation per step) and the recording forward (stage inputs) of the same geometry against the per-tile kernel
+    xs = x[:min(n, 1030)].to(DEV)
+    out, rec = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("NOCF_DUO", flag)
+        with torch.no_grad():
+            zF, cF = na.OCflow(xs, net, prob, [0.0, 1.0], 4, "rk4", m["alph"], intermediates=True)
+        assert (_kernel() == "rollout_duo_kernel") == (flag == "1")
+        out[flag] = (zF.cpu(), cF.cpu())
+        rec[flag] = _record(xs, net, prob, 3, m["alph"])
+        assert (_kernel() == "rollout_duo_kernel") == (flag == "1")
+    d = m["d"]
+    assert torch.equal(out["1"][0][:, :, 0], out["0"][0][:, :, 0]) and float(out["1"][1][:, :, 0].abs().max()) == 0.0
+    assert (out["1"][0][:, :d, :3] - out["0"][0][:, :d, :3]).abs().max().item() <= 2e-3
+    assert (out["1"][1][:, :, :3] - out["0"][1][:, :, :3]).abs().max().item() <= 2e-2 * out["0"][1].abs().max().item()
+    (_, zd, sd_, _), (_, zt, st_, _) = rec["1"], rec["0"]
+    assert torch.equal(sd_[0], st_[0]) and torch.equal(sd_[:, :, -1], st_[:, :, -1])
+    assert (sd_[:8] - st_[:8]).abs().max().item() <= 2e-3 and (sd_ != 0).any(dim=2).all()
     na.check_errors(sync=True)
 
 
@@ -534,17 +552,22 @@ def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, m
 
 @pytest.mark.parametrize("name,n,stepper,training", [("midcross20", 9, "rk4", True), ("swarm", 6, "rk4", True), ("swap12", 7, "rk1", True),
                                                       ("midcross30", 5, "rk4", False), ("softcorridor", 11, "rk4", True), ("swap2", 4, "rk4", True)])
-def test_tape_adjoint_on_other_problems_against_oracle_fp64_autograd(name, n, stepper, training):
+@pytest.mark.parametrize("width", [512, 256])
+def test_tape_adjoint_on_other_problems_against_oracle_fp64_autograd(name, n, stepper, training, width, form):
     """m = 512 networks on other Cross2D / SwarmTraj problems (2 ... 30 agents, obstacles of both kinds, pair and many-agent interaction
-    forms, d + 1 from 5 to 61): forward tape + split-role adjoint vs the oracle differentiated by torch autograd in float64"""
+    forms, d + 1 from 5 to 61): forward tape + split-role adjoint vs the oracle differentiated by torch autograd in float64.  m = 256: the
+    recording forward is the split-role kernel with four members per group (it writes the activation record), the adjoint the per-tile one
+    loading that record (`trainOC.py --m 256`)."""
+    if width == 256 and form == "g8":
+        pytest.skip("the 256-wide network has one geometry")
     alph = [100.0, 1.0e3, 50.0, 0.5, 0.25, 0.125]
     torch.manual_seed(11)
     prob, x0, _, _ = na.initProb(name, 24, 24, 0.5, alph, lambda t: t.float().to(DEV))
     prob.train() if training else prob.eval()
     x0 = x0[:n].contiguous()
     d = x0.shape[1]
-    sd = synth_state_dict(2, 512, d, seed=len(name))
-    net = na.Phi(nTh=2, m=512, d=d, alph=alph)
+    sd = synth_state_dict(2, width, d, seed=len(name))
+    net = na.Phi(nTh=2, m=width, d=d, alph=alph)
     net.load_state_dict(sd)
     net = net.to(DEV).train()
     nt = 4
@@ -553,7 +576,7 @@ def test_tape_adjoint_on_other_problems_against_oracle_fp64_autograd(name, n, st
     Jc.backward()
     torch.cuda.synchronize()
     na.check_errors(sync=True)
-    assert _kernel() == "rollout_duo_bwd_kernel"
+    assert _kernel() == ("rollout_duo_bwd_kernel" if width == 512 else "rollout_bwd_kernel")
     P = orc.PhiParams.from_state_dict({k: v.clone() for k, v in sd.items()}, dtype=torch.float64)
     for t in [*P.K, *P.b, P.w, P.A, P.cw, P.cb]:
         t.requires_grad_(True)
