@@ -95,7 +95,7 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates, means=None):
         ctrlFull = torch.empty(nt + 1, n, cdim, dtype=torch.float32, device=dev)
     alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
     with torch.cuda.device(dev):
-        L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents)
+        L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents, fwd=prob_st.kind != _lib.PROB_QUADCOPTER)
         if means is not None and hasattr(L, "nocf_rollout_means_f32"):
             rc = L.nocf_rollout_means_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
                                           float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
@@ -141,7 +141,7 @@ def _launch_segments(x, Phi, prob, t0s, t1, nts, rows_per_seg, stepper, alph, sl
     phi_st, keep1, ws = Phi._c_struct(n)
     prob_st, keep2 = prob._c_struct(x.device)
     dev = x.device
-    L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents)
+    L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents, fwd=prob_st.kind != _lib.PROB_QUADCOPTER)
     if not hasattr(L, "nocf_rollout_segments_f32"):
         return None
     slots = max(s0 + int(v) for s0, v in zip(slot0s, nts)) + 1

@@ -170,14 +170,18 @@ def _jit_start_background(key):
         return False
 
 
-def lib_for(d, m, nTh, r, n_agents):
-    """The library to run a rollout of this shape with.  The shipped one specialises the shapes of the reference's checkpoints and
+def lib_for(d, m, nTh, r, n_agents, fwd=False):
+    """The library to run a rollout of this shape with.  fwd: the call is a forward rollout (evaluation, intermediates, the recording
+    forward) -- two-layer networks of 129 ... 512 hidden units take the split-role kernel there, which only the SHIPPED library contains
+    (a per-shape build has the per-tile kernels only: it serves such a network's adjoint).  The shipped one specialises the shapes of the reference's checkpoints and
     initProb defaults (_BUILTIN_SHAPES) and takes any other shape with its generic instantiation; such a shape gets its own library --
     the same source compiled by hipcc with -DNOCF_XS_* (the plan as a compile-time constant: 1.3-1.8x on the tile kernels, no
     scratch), cached under csrc/jit/ -- automatically: see _jit_mode.  Same C ABI, same entry points."""
     key = (int(d), int(m), int(nTh), int(r), int(n_agents))
     mode = _jit_mode()
     if mode == "0" or key in _BUILTIN_SHAPES or "NOCF_LIB_PATH" in os.environ:
+        return lib()
+    if fwd and key[2] == 2 and 128 < key[1] <= 512 and os.environ.get("NOCF_DUO", "1") not in ("0",):
         return lib()
     L = _jit_libs.get(key)
     if L is not None:

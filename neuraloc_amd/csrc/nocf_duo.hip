@@ -121,7 +121,7 @@ template <int G_, int KBM_ = DU_KBM> struct DuoCfg {
 };
 
 struct DuoPlan {
-    int d, D1, r, nAg, NT, ngroups, spin_max, fast, G, KBM;
+    int d, D1, r, nAg, NT, ngroups, spin_max, fast, G, KBM, mReal;     // mReal: the network's hidden width; 16 KBM: the width the kernel runs (zero-padded)
     float hN, cb;
     int mapmode, ldsFloats;
     int dbg, dw;                   // dw: the adjoint with the two weight-gradient roles (32 workgroups per group)
@@ -150,7 +150,9 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
         const uint4 sen = make_uint4(DU_SENT, DU_SENT, DU_SENT, DU_SENT);
         for (long i = gid_; i < nx4; i += stride_) x4[i] = sen;
     }
-    const int m = 16 * dp.KBM, D1 = dp.D1;
+    // (a network of 129 ... 511 hidden units runs zero-padded to 256 / 512: a padded unit has K0 row, K1 row and column, b0, b1 and w all zero, so
+    // tanh(o) = 0 and v = 0 for it and it adds exact zeros to every sum it enters -- sigma(0) = log 2 is multiplied by a zero column of K1)
+    const int m = 16 * dp.KBM, mr = dp.mReal, D1 = dp.D1;
     // (the geometry of DuoCfg at run time: one pack kernel for all forms; every image has the same size in both forms of a width)
     const int G = dp.G, HPM = m / G, MTM = HPM / 16, KS = 4 / MTM, KBW = dp.KBM / KS, KB1 = DU_KBD / KS;
     const long nW = (long)G * 4 * KBW * 64, nK1 = (long)G * 4 * KB1 * 64, nK4 = (long)G * DU_KBD * MTM * 64;
@@ -169,7 +171,7 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
             const int o = HPM * c + 16 * (w % MTM) + (lane & 15);
             for (int e = 0; e < 4; ++e) {
                 const int k = 16 * ((w / MTM) * KBW + kb) + 4 * (lane >> 4) + e;
-                v[e] = third ? P.K[(long)k * m + o] : P.K[(long)o * m + k];
+                v[e] = (k < mr && o < mr) ? (third ? P.K[(long)k * mr + o] : P.K[(long)o * mr + k]) : 0.f;
             }
             dst = (third ? dp.oW3 : dp.oW2) + (third ? idx - nW : idx);
         } else if (idx < 2 * nW + nK1) {
@@ -180,7 +182,7 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
             const int o = HPM * c + 16 * (w % MTM) + (lane & 15);
             for (int e = 0; e < 4; ++e) {
                 const int k = 16 * ((w / MTM) * KB1 + kb) + 4 * (lane >> 4) + e;
-                v[e] = (k < D1) ? P.K0[(long)o * D1 + k] : 0.f;
+                v[e] = (k < D1 && o < mr) ? P.K0[(long)o * D1 + k] : 0.f;
             }
             dst = dp.oK1 + (idx - 2 * nW);
         } else {
@@ -191,7 +193,7 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
             const int dim = 16 * mt + (lane & 15);
             for (int e = 0; e < 4; ++e) {
                 const int i = HPM * cmem + 16 * kb + 4 * (lane >> 4) + e;
-                v[e] = (dim < D1) ? P.K0[(long)i * D1 + dim] : 0.f;
+                v[e] = (dim < D1 && i < mr) ? P.K0[(long)i * D1 + dim] : 0.f;
             }
             dst = dp.oK4 + (idx - 2 * nW - nK1);
         }
@@ -203,7 +205,7 @@ __global__ void duo_pack_kernel(DuoPlan dp, DevPhi P, float* __restrict__ ws, in
     }
     for (long i = gid; i < 3 * m; i += stride) {
         const int which = (int)(i / m), col = (int)(i % m);
-        ws[dp.oVec + i] = which == 0 ? P.b0[col] : (which == 1 ? P.b[col] : P.w[col]);
+        ws[dp.oVec + i] = col < mr ? (which == 0 ? P.b0[col] : (which == 1 ? P.b[col] : P.w[col])) : 0.f;
     }
     for (long i = gid; i < DU_DP; i += stride) ws[dp.oCW + i] = (i < D1) ? P.cw[i] : 0.f;
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DuoPlan) / 4) {
@@ -1442,14 +1444,17 @@ static int du_env_int(const char* name, int dflt) { return nocf_env_int(name, df
 long duo_rows_per_launch(void) { return 32L * 16 * DU_NTMAX; }
 
 // G: members per group of the forward (8: the form of rounds 3-4; 16: the fine form, DuoCfg); the adjoint always runs with 8
-// (m = 256: four members, the forward only; G is then ignored)
-static int make_duo_plan(int d, int m, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false, bool dw = false, int G = DU_G) {
-    if (nTh != 2 || (m != 64 * DU_G && m != 256) || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
-    if (m == 256) { if (bwd || dw) return NOCF_E_SHAPE; G = 4; }
+// (129 ... 256 hidden units: four members of 64, zero-padded to 256, the forward only -- G is then ignored; 257 ... 512: padded to 512; the
+// adjoint and the tape: exactly 512)
+static int make_duo_plan(int d, int m_real, int nTh, int r, int n_agents, long n, DuoPlan* out, bool bwd = false, bool dw = false, int G = DU_G) {
+    if (nTh != 2 || m_real <= 128 || m_real > 64 * DU_G || d + 1 > DU_DP || r > 16 || r < 1 || n < 1 || n_agents > 64 || n_agents < 1) return NOCF_E_SHAPE;
+    if ((bwd || dw) && m_real != 64 * DU_G) return NOCF_E_SHAPE;
+    const int m = m_real <= 256 ? 256 : 64 * DU_G;
+    if (m == 256) G = 4;
     else if ((G != DU_G && G != DU_GMAX) || (G != DU_G && (bwd || dw))) return NOCF_E_SHAPE;
     DuoPlan dp;
     memset(&dp, 0, sizeof(dp));
-    dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents; dp.G = G; dp.KBM = m / 16;
+    dp.d = d; dp.D1 = d + 1; dp.r = r; dp.nAg = n_agents; dp.G = G; dp.KBM = m / 16; dp.mReal = m_real;
     const long ntiles = (n + 15) / 16;
     dp.ngroups = (int)std::min<long>((dw ? 16 : 32) * DU_G / G, ntiles);     // (512 workgroups fill the chip: 32 groups of 16, 16 groups of 32 (dw, fine form))
     dp.dw = dw ? 1 : 0;
@@ -1518,8 +1523,10 @@ static int duo_pick_G(long n) {
 int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, float* ws, size_t ws_bytes, hipStream_t st,
                const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1) {
     if (pb.kind == NOCF_PROB_QUADCOPTER || (ra_in.zFull && ra_in.sAll)) return 1;
-    const bool narrow = phi->m == 256;                             // four members per group (DuoCfg): evaluation, intermediates, the recording forward
-    if (narrow && ra_in.tapeSc) return 1;                          // (no tape: the split-role ADJOINT exists for m = 512 only)
+    const bool narrow = phi->m <= 256;                             // four members per group (DuoCfg): evaluation, intermediates, the recording forward
+    const bool padded = phi->m != 256 && phi->m != 64 * DU_G;      // (zero-padded widths: evaluation and intermediates -- the records have the real width's row length)
+    if ((narrow || padded) && ra_in.tapeSc) return 1;              // (no tape: the split-role ADJOINT exists for m = 512 only)
+    if (padded && ra_in.sAll) return 1;
     const int GM = narrow ? 4 : duo_pick_G(ra_in.n);
     // (512 workgroups per launch: 32 groups of 16, 16 of 32, 64 of 8; up to four tiles per group, two with four own samples per member)
     const long chunk = narrow ? duo_rows_per_launch() : duo_rows_per_launch() * DU_G / GM;

@@ -2147,7 +2147,8 @@ size_t nocf_activation_record_floats(int32_t d, int32_t m, int32_t nTh, int64_t 
     if (nTh != 2 || n < 1 || nt < 1 || (stepper != NOCF_RK4 && stepper != NOCF_RK1)) return 0;
     // shapes with a recording kernel: the split-role kernel's (m = 512) and the one-CU kernel's (m <= 128 in whole 16-blocks, d+1 <= 16;
     // whether that kernel is taken also depends on the problem: `recorded` of the record call says so)
-    const bool duo = env_int("NOCF_DUO", 1) != 0 && duo_workspace_bytes(d, m, nTh, d + 1 < 10 ? d + 1 : 10, 1, n, &dummy) == 0;   // (m = 512 and 256)
+    const bool duo = (m == 512 || m == 256) && env_int("NOCF_DUO", 1) != 0 &&
+                     duo_workspace_bytes(d, m, nTh, d + 1 < 10 ? d + 1 : 10, 1, n, &dummy) == 0;   // (zero-padded widths: no record, its rows have the real width)
     const bool mono = env_int("NOCF_MONO", 1) != 0 && env_int("NOCF_MONO_REC", 1) != 0 && m <= 128 && (m % 16) == 0 && d + 1 <= 32 && m > 32;
     if (!duo && !mono) return 0;
     return (size_t)nt * ((stepper == NOCF_RK4) ? 4 : 1) * (size_t)n * (size_t)(4 * m + d + 1);

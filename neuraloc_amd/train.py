@@ -131,7 +131,7 @@ class _OCflowTrain(torch.autograd.Function):
         ctx.tape = None
         ctx.mid_rows = 0
         with torch.cuda.device(dev):
-            L = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+            L = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents, fwd=prob_st.kind != _lib.PROB_QUADCOPTER)      # (the recording forward; the adjoint below asks again)
             # Training tape (wide two-layer networks on the split-role kernel): the recording forward keeps what autograd would keep of the
             # unrolled graph -- u0, tanh(o), tanh(q), a, grad Phi and three scalars of every evaluation, the terminal one included, 2.9 GB for
             # swarm50 -- and the backward is the split-role adjoint (csrc/nocf_duo_bwd.inc).  NOCF_DUO_BWD=0: the per-tile adjoint below.

@@ -141,18 +141,21 @@ def test_duo_matches_tile_kernel_and_oracle_on_swarm50(n, training, variant, mon
     na.check_errors(sync=True)
 
 
-@pytest.mark.parametrize("width", [512, 256])
+@pytest.mark.parametrize("width", [512, 256, 384, 192, 130])
 @pytest.mark.parametrize("name,stepper,tspan,training", [
     ("swarm", "rk4", [0.0, 1.0], False), ("swarm", "rk1", [0.0, 1.0], True), ("midcross20", "rk4", [0.25, 0.9], True),
     ("swap12", "rk4", [0.0, 1.0], False), ("softcorridor", "rk4", [0.0, 1.0], True), ("swap2", "rk1", [0.1, 0.7], False),
     ("midcross30", "rk4", [0.0, 1.0], False), ("hardcorridor", "rk4", [0.0, 1.0], False)])
 def test_duo_on_other_point_agent_problems(name, stepper, tspan, training, width, form):
     """m = 512 and m = 256 networks (closed-form weights; src/Phi.py:16-52 is uniform in m) on Cross2D / SwarmTraj problems of other dimensions:
-    d+1 from 5 to 97.  The 256-wide network runs with four members of 64 hidden units per group (DuoCfg<4, 16>), four own samples per member."""
+    d+1 from 5 to 97.  The 256-wide network runs with four members of 64 hidden units per group (DuoCfg<4, 16>), four own samples per member;
+    every other width between 129 and 511 runs zero-padded to 256 or 512 (a padded unit adds exact zeros)."""
     if name not in na.initProb.__globals__["PROBLEM_NAMES"]:
         pytest.skip("not an initProb problem")
-    if width == 256 and form == "g8":
-        pytest.skip("the 256-wide network has one geometry")
+    if width <= 256 and form == "g8":
+        pytest.skip("networks of up to 256 hidden units have one geometry")
+    if width not in (512, 256) and (stepper != "rk4" or name in ("midcross30", "hardcorridor")):
+        pytest.skip("the padded widths run on a subset of the problems")
     torch.manual_seed(11)
     prob, x0, _, _ = na.initProb(name, 37, 8, 0.5, ALPH, lambda t: t.float().to(DEV))
     prob.train() if training else prob.eval()
