@@ -89,18 +89,20 @@ def test_duo_kernel_is_the_default_for_swarm50(monkeypatch):
     assert _kernel().startswith("rollout_kernel")
 
 
-@pytest.mark.parametrize("n", [1, 5, 16, 17, 39, 100, 512, 513, 1000, 1024, 1025, 2048, 2049, 4096])
+@pytest.mark.parametrize("n", [1, 5, 16, 17, 39, 100, 128, 256, 512, 513, 1000, 1024, 1025, 2048, 2049, 4096])
 @pytest.mark.parametrize("training", [False, True])
 @pytest.mark.parametrize("variant", ["default", "write-through", "static-map"])
-def test_duo_matches_tile_kernel_and_oracle_on_swarm50(n, training, variant, monkeypatch):
+def test_duo_matches_tile_kernel_and_oracle_on_swarm50(n, training, variant, monkeypatch, form):
     """pretrained swarm50 network, batches that fill 1..32 groups with one to four sample tiles and more than one launch (ragged
     tails included); both exchange forms (default: same-XCD groups keep their payload in L2; write-through everywhere) and both
     role maps (default: the CU census pairs the two roles of a member on one CU; static).
     A few of these states are chaotic at nt = 10 (a 1e-6 relative change of x moves their terminal cost by 2 %, in the oracle
     too), so per-sample rows may differ between two correct fp32 evaluations: such rows are counted and bounded, the batch means
     must agree."""
-    if variant != "default" and n not in (5, 100, 1024, 2049):
+    if variant != "default" and n not in ((5, 100, 1024, 2049) if form == "g8" else (5, 100, 256)):
         pytest.skip("the exchange / map variants run on a subset of the sizes")
+    if form == "g16" and n in (513, 1024, 1025, 2048, 4096):
+        pytest.skip("the fine geometry is the library's choice up to 256 rows; forced beyond, it runs 512 / 1000 / 2049 rows (two to four tiles per group, a second launch)")
     g = load_golden("swarm50")
     net, prob = make_net(g, DEV), make_prob(g, DEV, training=training)
     m = g.meta
