@@ -693,6 +693,24 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     const int nstage = (ra.stepper == NOCF_RK4) ? 4 : 1;
     const long rowg = (long)group * 16 * NT;                    // first row (of this launch) of the group
     auto own_row = [&](int t, int j) -> long { return rowg + 16 * t + SPM * member + j; };
+    // The activation record's stores (training, REC): every wave writes the 4 features it holds of 16 samples, four times per tile and evaluation.
+    // As 64-bit pointer arithmetic per lane that was ~10 vector instructions per store and 20 spilled registers in the recording instantiation;
+    // here the evaluation's block of a section is a BUFFER whose base the scalar unit forms (section, evaluation: wave-uniform), and the lane adds a
+    // 32-bit offset (row, feature) -- rows beyond the batch get an offset beyond the buffer, which drops the store.
+    auto rec_block = [&](int section, long eidx) -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc(ra.act + (long)section * ra.actRows * MW + (eidx * rr.n_total + rr.row0) * MW, 0,
+                                                 (int)((rr.n_total - rr.row0) * MW * 4), 0x00020000);
+    };
+    auto rec_off = [&](int t) -> int {                           // this lane's byte offset in such a block: sample lane & 15 of tile t, features HPM member + 16 ft + 4 slot
+        const long rw = rowg + 16 * t + (lane & 15);
+        return rw < ra.n ? (int)((rw * MW + HPM * member + 16 * ft + 4 * slot) * 4) : -1;
+    };
+    auto rec_store = [&](__amdgpu_buffer_rsrc_t rs, int off, float a, float b, float c, float d_) {
+        u32x4 u;
+        u.x = __float_as_uint(a); u.y = __float_as_uint(b); u.z = __float_as_uint(c); u.w = __float_as_uint(d_);
+        __builtin_amdgcn_raw_buffer_store_b128(u, rs, off, 0, 0);
+        DU_STORE_GUARD(u);
+    };
 
     if (role == 0) {
         // =====================================================================================================
@@ -1039,12 +1057,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         if (KS == 1 || kh == 0) du_st(g, vb, xU + fo, sg);
                         if (KS == 1 || kh == 1) du_st(g, vb, xT + fo, th);
                         if (REC && ra.act && (!fin || ra.tapeSc)) {    // activation record: 4 features of sample lane & 15 (64-byte runs per sample)
-                            const long rw = rowg + 16 * t + (lane & 15);
-                            if (rw < ra.n) {
-                                float* dst = ra.act + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * MW + HPM * member + 16 * ft + 4 * slot;
-                                if (KS == 1 || kh == 0) *reinterpret_cast<float4*>(dst) = make_float4(sg[0], sg[1], sg[2], sg[3]);
-                                if (KS == 1 || kh == 1) *reinterpret_cast<float4*>(dst + ra.actRows * MW) = make_float4(th[0], th[1], th[2], th[3]);
-                            }
+                            const int ro = rec_off(t);
+                            if (KS == 1 || kh == 0) rec_store(rec_block(0, e - 1), ro, sg[0], sg[1], sg[2], sg[3]);
+                            if (KS == 1 || kh == 1) rec_store(rec_block(1, e - 1), ro, th[0], th[1], th[2], th[3]);
                         }
                     }
                     DTL(40 * t + 7);
@@ -1095,12 +1110,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         if (KS == 1 || kh == 0) du_st(g, vb, xV + ((par * NT + t) * KBM + MTM * member + ft) * 1024, v);
                         du_anchor(g, t, lane);                  // (predictive waiting: this wave's next waits for tile t count from here)
                         DTL(40 * t + 12);
-                        if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 0)) {    // activation record: tanh(q)
-                            const long rw = rowg + 16 * t + (lane & 15);
-                            if (rw < ra.n)
-                                *reinterpret_cast<float4*>(ra.act + 2 * ra.actRows * MW + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * MW
-                                                           + HPM * member + 16 * ft + 4 * slot) = make_float4(tq[0], tq[1], tq[2], tq[3]);
-                        }
+                        if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 0))      // activation record: tanh(q)
+                            rec_store(rec_block(2, e - 1), rec_off(t), tq[0], tq[1], tq[2], tq[3]);
                         if (fin && (KS == 1 || kh == 1)) {     // (fine form: the wave that does not publish v takes the value's part)
                             // w . u_1 = w . (u_0 + hN sigma(q)) over this wave's 16 features (src/Phi.py:91-96): own u_0 fragment from the staged tile
                             const float4 u4 = L4[(DA_UF >> 2) + (MTM * member + ft) * 64 + lane];
@@ -1324,12 +1335,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     y.x = th[0] * a4.x; y.y = th[1] * a4.y;
                     y.z = th[2] * a4.z; y.w = th[3] * a4.w;
                     if (KS == 1 || kh == 0) L4[(DB_YF >> 2) + ft * 64 + lane] = y;
-                    if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 1)) {        // activation record: a = w + hN K1' v
-                        const long rw = rowg + 16 * t + (lane & 15);
-                        if (rw < ra.n)
-                            *reinterpret_cast<float4*>(ra.act + 3 * ra.actRows * MW + (((long)(e - 1)) * rr.n_total + rr.row0 + rw) * MW
-                                                       + HPM * member + 16 * ft + 4 * slot) = a4;
-                    }
+                    if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 1))          // activation record: a = w + hN K1' v
+                        rec_store(rec_block(3, e - 1), rec_off(t), a4.x, a4.y, a4.z, a4.w);
                 }
                 DTL(40 * t + 27);
                 // (in front of the barrier: they do not depend on y, and the other waves' epilogues cover them)
@@ -1527,6 +1534,7 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
     const bool padded = phi->m != 256 && phi->m != 64 * DU_G;      // (zero-padded widths: evaluation and intermediates -- the records have the real width's row length)
     if ((narrow || padded) && ra_in.tapeSc) return 1;              // (no tape: the split-role ADJOINT exists for m = 512 only)
     if (padded && ra_in.sAll) return 1;
+    if (ra_in.act && (long)ra_in.n * 512 * 4 >= (1L << 31)) return 1;      // (the record's per-evaluation blocks are addressed with 32-bit offsets)
     const int GM = narrow ? 4 : duo_pick_G(ra_in.n);
     // (512 workgroups per launch: 32 groups of 16, 16 of 32, 64 of 8; up to four tiles per group, two with four own samples per member)
     const long chunk = narrow ? duo_rows_per_launch() : duo_rows_per_launch() * DU_G / GM;

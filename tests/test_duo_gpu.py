@@ -13,7 +13,7 @@ import neuraloc_amd as na
 from neuraloc_amd import _lib
 from oracle import ocflow_oracle as orc
 from conftest import load_golden
-from util_hip import closed_form_normal, count_off, make_net, make_oracle, make_prob, synth_state_dict
+from util_hip import closed_form_normal, count_off, make_net, make_oracle, make_prob, poison_allocator, synth_state_dict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -501,6 +501,7 @@ def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt,
         net = make_net(g, DEV).train()
         prob = make_prob(g, DEV, training=True)
         xx = x.clone().requires_grad_(True)
+        poison_allocator(DEV, big=2)
         Jc, _ = na.OCflow(xx, net, prob, [0.0, 1.0], nt, stepper, m["alph"])
         assert _kernel() == "rollout_duo_kernel"
         Jc.backward()
@@ -516,13 +517,14 @@ def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt,
     assert float((a[2] - b[2]).abs().max()) <= 2e-4 * float(b[2].abs().max()) + 1e-12
 
 
-@pytest.mark.parametrize("n,nt,stepper,training", [(16, 3, "rk4", True), (37, 2, "rk4", False), (530, 2, "rk4", True), (20, 5, "rk1", True)])
+@pytest.mark.parametrize("n,nt,stepper,training", [(16, 3, "rk4", True), (37, 2, "rk4", False), (530, 2, "rk4", True), (20, 5, "rk1", True), (300, 2, "rk4", True)])
 def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, monkeypatch):
     """the split-role adjoint -- with the weight gradients contracted from the row streams (default) and accumulated in the kernel by the
     weight-gradient roles (NOCF_DUO_DW=1) -- against BOTH per-tile adjoints (with the activation record and recomputing) on the pretrained swarm50 network
     with every multiplier switched on (the checkpoint trains with alph[3:6] = 0: HJt / HJfin / HJgrad exercise the sign masks, the
     terminal block and the value's rows) and the swarm squeezed so that agents interact and sit inside the obstacles' supports
-    (the physics pass of role B' runs; unsqueezed most rows skip it)."""
+    (the physics pass of role B' runs; unsqueezed most rows skip it).  n = 300 with the weight-gradient roles: 16 groups of which six have no rows
+    (their clamped addresses point into another group's rows); the allocator's free blocks are filled with NaN in front of every variant."""
     g = load_golden("swarm50")
     m = g.meta
     alph = list(m["alph"])
@@ -538,6 +540,7 @@ def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, m
         net = make_net(g, DEV).train()
         prob = make_prob(g, DEV, training=training)
         xx = x.clone().requires_grad_(True)
+        poison_allocator(DEV)                                      # (a row read before it is written must not find the previous variant's values)
         Jc, _ = na.OCflow(xx, net, prob, [0.0, 1.0], nt, stepper, alph)
         Jc.backward()
         torch.cuda.synchronize()

@@ -17,7 +17,7 @@ import torch
 import neuraloc_amd as na
 from neuraloc_amd import _lib
 from oracle import ocflow_oracle as orc
-from util_hip import count_off, full_states, make_net, make_oracle, make_prob
+from util_hip import count_off, full_states, make_net, make_oracle, make_prob, poison_allocator
 
 pytestmark = pytest.mark.gpu
 def load_golden_by_name(name):
@@ -384,6 +384,7 @@ def test_backward_matches_reference_parameter_gradients(name):
     net.train()
     prob = make_prob(g, DEV, training=True)
     x = g.t("x")[:ns].to(DEV)
+    poison_allocator(DEV, big=2)                                    # (records and row streams start as NaN, not as an earlier test's values)
     Jc, cs = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", g.meta["alph"])
     J64 = float(G[f"{name}/Jc64"])
     assert abs(Jc.item() - J64) <= 1e-5 * abs(J64)
@@ -417,6 +418,9 @@ def test_backward_at_training_size_matches_reference_parameter_gradients(name, b
     prob = make_prob(g, DEV, training=True)
     x = full_states(g, int(G[f"{name}/seed"])).to(DEV)
     assert x.shape[0] == n
+    big = torch.full((1 << 30,), float("nan"), device=DEV)          # (4 GiB of NaN for the tape and the row streams to be carved from)
+    del big
+    poison_allocator(DEV, big=2)
     Jc, cs = na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", g.meta["alph"])
     J64, J32 = float(G[f"{name}/Jc64"]), float(G[f"{name}/Jc"])
     assert abs(Jc.item() - J64) <= 4 * abs(J32 - J64) + 1e-5 * abs(J64), (Jc.item(), J32, J64)

@@ -77,3 +77,14 @@ def synth_state_dict(nTh, m, d, seed):
         sd[f"N.layers.{l}.weight"] = fill(m, m, 0.29 + 0.01 * l, 0.17, 0.5 + seed + l, 1.0 / m ** 0.5)
         sd[f"N.layers.{l}.bias"] = fill(1, m, 0.0, 0.27, 0.6 + seed + l, 0.1).reshape(m)
     return sd
+
+
+def poison_allocator(dev, big=4):
+    """Fill what torch's caching allocator will hand out next with NaN: blocks of every pool size are allocated, filled and freed.  A kernel
+    that reads a row before its producer wrote it (or a row nobody writes) then computes with NaN instead of with the previous, identical
+    run's values -- the repeated runs of one test would otherwise hide exactly that (found this way: the weight-gradient roles' clamped rows)."""
+    ts = [torch.full((1 << 28,), float("nan"), device=dev) for _ in range(big)]
+    for words, cnt in ((1 << 12, 100), (1 << 14, 100), (1 << 16, 100), (77312, 50), (200000, 50), (1 << 18, 40), (1 << 20, 30), (1 << 21, 30), (1 << 23, 12), (1 << 25, 6)):
+        ts += [torch.full((words,), float("nan"), device=dev) for _ in range(cnt)]
+    torch.cuda.synchronize(dev)
+    del ts
