@@ -64,3 +64,14 @@ def golden(request):
 @pytest.fixture(params=PRETRAINED)
 def golden_pretrained(request):
     return load_golden(request.param)
+
+
+@pytest.fixture(autouse=True)
+def _nan_filled_free_blocks(request):
+    """NOCF_TEST_POISON=1 (a debugging run of the GPU suite, not the default -- it adds ~1 s per test): the caching allocator's free blocks are
+    filled with NaN in front of every GPU test, so a kernel that reads a row nobody wrote (or reads it before its producer) computes with NaN
+    instead of with an earlier test's values.  The tape / adjoint tests do this themselves, always (tests/util_hip.poison_allocator)."""
+    if os.environ.get("NOCF_TEST_POISON", "0") == "1" and request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available():
+        from util_hip import poison_allocator
+        poison_allocator(torch.device("cuda:0"), big=2)
+    yield

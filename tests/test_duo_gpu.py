@@ -594,7 +594,7 @@ def test_tape_adjoint_on_other_problems_against_oracle_fp64_autograd(name, n, st
     J.backward()
     want = {"A": P.A.grad, "c.weight": P.cw.grad, "c.bias": P.cb.grad, "w.weight": P.w.grad,
             "N.layers.0.weight": P.K[0].grad, "N.layers.0.bias": P.b[0].grad, "N.layers.1.weight": P.K[1].grad, "N.layers.1.bias": P.b[1].grad}
-    assert abs(Jc.item() - float(J)) <= 2e-5 * abs(float(J))
+    assert abs(Jc.detach().item() - float(J)) <= 2e-5 * abs(float(J))
     for k, p in net.named_parameters():
         w = want[k] if want[k] is not None else torch.zeros_like(p, dtype=torch.float64).cpu()
         scale = w.abs().max().item()
