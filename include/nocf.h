@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NOCF_VERSION 110            /* major*100 + minor */
+#define NOCF_VERSION 111            /* major*100 + minor */
 
 #define NOCF_E_NULL      (-1)       /* required pointer is NULL                     */
 #define NOCF_E_SHAPE     (-2)       /* d/m/nTh/n/nt out of the supported range      */
@@ -290,6 +290,20 @@ int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t 
                               float* dK1, float* dK0, float* dw_scratch, size_t dw_scratch_floats, int32_t* dw_done,
                               void* workspace, size_t workspace_bytes, void* stream);
 size_t nocf_dw_scratch_floats(void);
+/*
+ * nocf_rollout_bwd_tape_sums_f32 = nocf_rollout_bwd_tape_f32 with the COLUMN SUMS formed in the kernel (round 5): the epilogues that hold the dw rows,
+ * qbar and obar add them up (16 rows across a DPP row, then per wave in LDS; rows beyond the batch add nothing) and every group writes one partial:
+ *     colsum   device [G, 3, m], G = colsum_floats / (3 m) >= nocf_bwd_colsum_floats(n) / (3 m):  (colsum Wb | colsum Qb | colsum Ob) per group of
+ *              every launch, zero for the rest; the caller sums over G in index order (fixed order: deterministic).
+ * The dw rows are then not streamed at all (no Wb: [R, m] floats less to allocate and to write) and db1 / db0 / dw need no pass over Qb / Ob / Wb.
+ * As in nocf_rollout_bwd_tape_f32 the value's rows are not in them: the caller adds phib'(tanh(q).w), phib'Y and phib'u_1 of the terminal block's n rows.
+ */
+size_t nocf_bwd_colsum_floats(int64_t n);
+int nocf_rollout_bwd_tape_sums_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
+                                   const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                                   const float* tape, float* Y, float* Ab, float* Qb, float* Ob, float* Gb, float* lam0,
+                                   float* dK1, float* dK0, float* dw_scratch, size_t dw_scratch_floats, int32_t* dw_done,
+                                   float* colsum, size_t colsum_floats, void* workspace, size_t workspace_bytes, void* stream);
 int nocf_poison_if_failed_f32(float* buf, int64_t count, void* stream);
 
 /*

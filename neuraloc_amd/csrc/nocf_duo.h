@@ -30,8 +30,12 @@ struct DuoBwdHost {
     // optional: dK1 [m][m] and dK0 [m][d+1] accumulated in the kernel (the weight-gradient roles), with a scratch buffer of
     // duo_dw_scratch_floats() floats for the groups' partial sums; *dw_done = 1 when that kernel ran
     float *dK1, *dK0, *dw_scratch; size_t dw_scratch_floats; int* dw_done;
+    // optional: the column sums of the dw rows, qbar and obar formed in the kernel's epilogues -- [G][3][m] partials, G = csum_floats / (3 m) >=
+    // duo_bwd_colsum_floats(n) / (3 m), zeroed here, to be summed over G in index order by the caller.  With it Wb may be null (not streamed).
+    float* csum; size_t csum_floats;
 };
 size_t duo_dw_scratch_floats(void);
+size_t duo_bwd_colsum_floats(long n);
 int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, float* ws, size_t ws_bytes, hipStream_t st,
                    const unsigned** errp, int debug, hipEvent_t ev0, hipEvent_t ev1);
 

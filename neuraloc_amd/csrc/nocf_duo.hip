@@ -1470,7 +1470,8 @@ static int make_duo_plan(int d, int m_real, int nTh, int r, int n_agents, long n
     dp.hN = 1.0f;
     if (bwd && r > 10) return NOCF_E_SHAPE;                                        // (the adjoint keeps 10 rows of A in LDS)
     const int fine = G == DU_GMAX ? 1024 : 0;                                      // (the waves' partial sums: see the kernel)
-    const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE : DA_T + fine + 4 * DPW_WORDS + (16 / G) * dp.NT * DS_STRIDE, ldsB = DB_END + (bwd ? 0 : 4 * DPW_WORDS);
+    // (adjoint: + the column-sum cells of the epilogues, 2 x 64 floats behind role A's carve and 64 behind role B's)
+    const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE + 128 : DA_T + fine + 4 * DPW_WORDS + (16 / G) * dp.NT * DS_STRIDE, ldsB = DB_END + (bwd ? 64 : 4 * DPW_WORDS);
     dp.ldsFloats = std::max(std::max(ldsA, ldsB), dw ? DC_END : 0);
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
     long o = 0;                                                                    // floats
@@ -1637,6 +1638,13 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
     }
     DevPhi P{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
     const int nstage = (h.stepper == NOCF_RK4) ? 4 : 1;
+    if (!h.csum && !h.Wb) return 1;
+    if (h.csum) {                                                  // the launches' groups write their partials one behind the other; rows nobody writes stay 0
+        if (h.csum_floats < duo_bwd_colsum_floats(h.n)) return 1;
+        e = hipMemsetAsync(h.csum, 0, h.csum_floats * sizeof(float), st);
+        if (e) return (int)e;
+    }
+    long gbase = 0;
     for (long r0 = 0; r0 < h.n; r0 += chunk) {
         const long cn = std::min<long>(chunk, h.n - r0);
         DuoPlan dp;
@@ -1658,6 +1666,8 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
         ba.stamps = h.stamps;
         ba.dK1p = dw ? h.dw_scratch : nullptr;
         ba.dK0p = dw ? h.dw_scratch + (size_t)2 * 16 * 512 * 512 : nullptr;
+        ba.csum = h.csum ? h.csum + (size_t)gbase * 3 * 512 : nullptr;
+        gbase += dp.ngroups;
         DuoRun rr{r0, h.n};
         const DuoPlan* dpp = reinterpret_cast<const DuoPlan*>(ws + dp.oPlan);
         const size_t ldsBytes = (size_t)dp.ldsFloats * 4;
@@ -1680,3 +1690,5 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
 }
 
 size_t duo_dw_scratch_floats(void) { return (size_t)2 * 16 * 512 * (512 + DU_DP); }
+// [groups of all launches][3][512]: at most 32 groups per 512 rows (the launches of the kernel with the weight-gradient roles take 512 rows and 16 groups)
+size_t duo_bwd_colsum_floats(long n) { return (size_t)((n + 511) / 512) * 32 * 3 * 512; }

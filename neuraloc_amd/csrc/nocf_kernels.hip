@@ -2222,22 +2222,32 @@ size_t nocf_dw_scratch_floats(void) {
 #endif
 }
 
-int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
-                              const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
-                              const float* tape, float* Y, float* Ab, float* Wb, float* Qb, float* Ob, float* Gb, float* lam0,
-                              float* dK1, float* dK0, float* dw_scratch, size_t dw_scratch_floats, int32_t* dw_done,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+size_t nocf_bwd_colsum_floats(int64_t n) {
+#ifdef NOCF_JIT_ONLY
+    (void)n;
+    return 0;
+#else
+    return n < 1 ? 0 : duo_bwd_colsum_floats((long)n);
+#endif
+}
+
+static int bwd_tape_impl(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
+                         const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                         const float* tape, float* Y, float* Ab, float* Wb, float* Qb, float* Ob, float* Gb, float* lam0,
+                         float* dK1, float* dK0, float* dw_scratch, size_t dw_scratch_floats, int32_t* dw_done,
+                         float* colsum, size_t colsum_floats, void* workspace, size_t workspace_bytes, void* stream) {
     if (dw_done) *dw_done = 0;
 #ifdef NOCF_JIT_ONLY
-    (void)dK1; (void)dK0; (void)dw_scratch; (void)dw_scratch_floats;
+    (void)dK1; (void)dK0; (void)dw_scratch; (void)dw_scratch_floats; (void)colsum; (void)colsum_floats;
     (void)phi; (void)prob; (void)n; (void)nt; (void)stepper; (void)alph; (void)inv_n; (void)s_all; (void)z_final; (void)hs; (void)tape;
     (void)Y; (void)Ab; (void)Wb; (void)Qb; (void)Ob; (void)Gb; (void)lam0; (void)workspace; (void)workspace_bytes; (void)stream;
     return NOCF_E_SHAPE;
 #else
     int rc = check_phi(phi);
     if (rc) return rc;
-    if (!alph || !s_all || !z_final || !hs || !tape || !Y || !Ab || !Wb || !Qb || !Ob || !Gb || !workspace) return NOCF_E_NULL;
+    if (!alph || !s_all || !z_final || !hs || !tape || !Y || !Ab || (!Wb && !colsum) || !Qb || !Ob || !Gb || !workspace) return NOCF_E_NULL;
     if (n < 1 || nt < 1) return NOCF_E_SHAPE;
+    if (colsum && colsum_floats < nocf_bwd_colsum_floats(n)) return NOCF_E_WORKSPACE;
     if (stepper != NOCF_RK4 && stepper != NOCF_RK1) return NOCF_E_STEPPER;
     DevProb pb;
     rc = fill_prob(prob, phi->d, &pb);
@@ -2245,6 +2255,7 @@ int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t 
     size_t oU1, oSc, tot;
     tape_offsets(phi->d, phi->m, n, nt, stepper, &oU1, &oSc, &tot);
     DuoBwdHost h;
+    h.csum = colsum; h.csum_floats = colsum_floats;
     h.s_all = s_all; h.z_final = z_final; h.hs = hs; h.tape = tape; h.tapeU1 = tape + oU1; h.tapeSc = tape + oSc;
     h.n = n; h.nt = nt; h.stepper = stepper;
     h.a0 = alph[0]; h.a3 = alph[3]; h.a4 = alph[4]; h.a5 = alph[5]; h.inv_n = (float)inv_n;
@@ -2265,6 +2276,25 @@ int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t 
     if (g_prof_on) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
     return rc == 1 ? NOCF_E_SHAPE : rc;
 #endif
+}
+
+int nocf_rollout_bwd_tape_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
+                              const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                              const float* tape, float* Y, float* Ab, float* Wb, float* Qb, float* Ob, float* Gb, float* lam0,
+                              float* dK1, float* dK0, float* dw_scratch, size_t dw_scratch_floats, int32_t* dw_done,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return bwd_tape_impl(phi, prob, n, nt, stepper, alph, inv_n, s_all, z_final, hs, tape, Y, Ab, Wb, Qb, Ob, Gb, lam0,
+                         dK1, dK0, dw_scratch, dw_scratch_floats, dw_done, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+int nocf_rollout_bwd_tape_sums_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper,
+                                   const float* alph, double inv_n, const float* s_all, const float* z_final, const float* hs,
+                                   const float* tape, float* Y, float* Ab, float* Qb, float* Ob, float* Gb, float* lam0,
+                                   float* dK1, float* dK0, float* dw_scratch, size_t dw_scratch_floats, int32_t* dw_done,
+                                   float* colsum, size_t colsum_floats, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!colsum) return NOCF_E_NULL;
+    return bwd_tape_impl(phi, prob, n, nt, stepper, alph, inv_n, s_all, z_final, hs, tape, Y, Ab, nullptr, Qb, Ob, Gb, lam0,
+                         dK1, dK0, dw_scratch, dw_scratch_floats, dw_done, colsum, colsum_floats, workspace, workspace_bytes, stream);
 }
 
 int nocf_rollout_bwd_f32(const NocfPhi* phi, const NocfProb* prob, int64_t n, int32_t nt, int32_t stepper, double t1,

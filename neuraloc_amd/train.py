@@ -306,9 +306,14 @@ class _OCflowTrain(torch.autograd.Function):
         hs = _step_sizes(ctx.tspan, nt).to(dev)
         alph_c = (C.c_float * 6)(*[float(a) for a in alph[:6]])
         lam0 = torch.empty(n, d, device=dev) if ctx.x_needs_grad else None
-        Y, Ab, Wb, Qb, Ob = (torch.empty(R, m, device=dev) for _ in range(5))
+        Y, Ab, Qb, Ob = (torch.empty(R, m, device=dev) for _ in range(4))
         Gb = torch.empty(R, D1, device=dev)
         lib = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+        # the column sums (dw rows, qbar, obar -> dw, db1, db0) come from the kernel's epilogues: no Wb stream, no pass over Qb / Ob for the biases
+        # (NOCF_DUO_CSUM=0: the dw rows are streamed and all three are summed afterwards, as up to round 4)
+        csum_on = os.environ.get("NOCF_DUO_CSUM", "1") != "0"
+        Wb = None if csum_on else torch.empty(R, m, device=dev)
+        cs = torch.empty(int(lib.nocf_bwd_colsum_floats(n)), device=dev) if csum_on else None
         # NOCF_DUO_DW=1: the two large weight gradients are accumulated in the kernel (weight-gradient roles, nocf_duo_bwd.inc); measured
         # slower than contracting the streams afterwards, so the default contracts them below
         dK1, dK0 = torch.empty(m, m, device=dev), torch.empty(m, D1, device=dev)
@@ -318,11 +323,18 @@ class _OCflowTrain(torch.autograd.Function):
             sc_dw = _SCRATCH[("dw", dev)] = torch.empty(max(nsc, 1), device=dev)
         dw_done = C.c_int32(0)
         with torch.cuda.device(dev):
-            rc = lib.nocf_rollout_bwd_tape_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper], alph_c,
-                                               1.0 / float(ctx.n_total), _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(tape),
-                                               _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Wb), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb),
-                                               _lib.ptr(lam0), _lib.ptr(dK1), _lib.ptr(dK0), _lib.ptr(sc_dw), sc_dw.numel(), C.byref(dw_done),
-                                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            if csum_on:
+                rc = lib.nocf_rollout_bwd_tape_sums_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper], alph_c,
+                                                        1.0 / float(ctx.n_total), _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(tape),
+                                                        _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb),
+                                                        _lib.ptr(lam0), _lib.ptr(dK1), _lib.ptr(dK0), _lib.ptr(sc_dw), sc_dw.numel(), C.byref(dw_done),
+                                                        _lib.ptr(cs), cs.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            else:
+                rc = lib.nocf_rollout_bwd_tape_f32(C.byref(phi_st), C.byref(prob_st), n, int(nt), _STEPPERS[ctx.stepper], alph_c,
+                                                   1.0 / float(ctx.n_total), _lib.ptr(s_all), _lib.ptr(z_out), _lib.ptr(hs), _lib.ptr(tape),
+                                                   _lib.ptr(Y), _lib.ptr(Ab), _lib.ptr(Wb), _lib.ptr(Qb), _lib.ptr(Ob), _lib.ptr(Gb),
+                                                   _lib.ptr(lam0), _lib.ptr(dK1), _lib.ptr(dK0), _lib.ptr(sc_dw), sc_dw.numel(), C.byref(dw_done),
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         if rc == -2:
             return None
         _lib.check(rc, "nocf_rollout_bwd_tape_f32")
@@ -337,16 +349,22 @@ class _OCflowTrain(torch.autograd.Function):
         # the value's rows (weight gradients only: the state's share of this cotangent is already in the terminal lambda) ride on the
         # terminal block: qbar += phib v, obar += phib y, dw row += phib u_1
         u1 = tape[4 * R * m + gpad:4 * R * m + gpad + n * m].view(n, m)
-        Qb[R - n:].addcmul_(TH1[R - n:] * w.t(), phib[:, None])
+        vT = TH1[R - n:] * w.t()
+        if csum_on:                                               # kernel sums (without the value's rows) + the value's rows of the terminal block
+            S = cs.view(-1, 3, m).sum(0)
+            gw, gb1, gb0 = S[0] + phib @ u1, S[1] + phib @ vT, S[2] + phib @ Y[R - n:]
+        Qb[R - n:].addcmul_(vT, phib[:, None])
         Ob[R - n:].addcmul_(Y[R - n:], phib[:, None])
-        Wb[R - n:].addcmul_(u1, phib[:, None])
+        if not csum_on:
+            Wb[R - n:].addcmul_(u1, phib[:, None])
+            gw, gb1, gb0 = _colsum(Wb), _colsum(Qb), _colsum(Ob)
         if dw_done.value:                                         # (the kernel's sums include the value's rows)
             gK0, gK1 = dK0, dK1
         else:
             gK0, gK1 = _contract(Ob, Sx, _contract(Y, Gb)), _contract(Qb, U0, w * _contract(TH1, Ab))
-        grads = {"N.layers.0.weight": gK0, "N.layers.0.bias": _colsum(Ob),
-                 "N.layers.1.weight": gK1, "N.layers.1.bias": _colsum(Qb),
-                 "w.weight": _colsum(Wb).reshape(1, -1),
+        grads = {"N.layers.0.weight": gK0, "N.layers.0.bias": gb0,
+                 "N.layers.1.weight": gK1, "N.layers.1.bias": gb1,
+                 "w.weight": gw.reshape(1, -1),
                  "c.weight": (_colsum(Gb) + phib @ sT).reshape(1, -1), "c.bias": phib.sum().reshape(1)}
         dM = _contract(Gb, Sx) + 0.5 * (sT * phib[:, None]).t() @ sT
         grads["A"] = net.A.detach() @ (dM + dM.t())

@@ -520,7 +520,8 @@ def test_activation_record_gives_the_gradients_of_the_recomputing_adjoint(n, nt,
 @pytest.mark.parametrize("n,nt,stepper,training", [(16, 3, "rk4", True), (37, 2, "rk4", False), (530, 2, "rk4", True), (20, 5, "rk1", True), (300, 2, "rk4", True)])
 def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, monkeypatch):
     """the split-role adjoint -- with the weight gradients contracted from the row streams (default) and accumulated in the kernel by the
-    weight-gradient roles (NOCF_DUO_DW=1) -- against BOTH per-tile adjoints (with the activation record and recomputing) on the pretrained swarm50 network
+    weight-gradient roles (NOCF_DUO_DW=1); with the column sums (dw, db1, db0) formed in the kernel's epilogues (default) and summed from the
+    streamed rows afterwards (NOCF_DUO_CSUM=0) -- against BOTH per-tile adjoints (with the activation record and recomputing) on the pretrained swarm50 network
     with every multiplier switched on (the checkpoint trains with alph[3:6] = 0: HJt / HJfin / HJgrad exercise the sign masks, the
     terminal block and the value's rows) and the swarm squeezed so that agents interact and sit inside the obstacles' supports
     (the physics pass of role B' runs; unsqueezed most rows skip it).  n = 300 with the weight-gradient roles: 16 groups of which six have no rows
@@ -531,10 +532,12 @@ def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, m
     alph[3], alph[4], alph[5] = 2.0, 3.0, 1.5
     x = (0.3 * (g.t("xInit") + m["var0"] * closed_form_normal(n, m["d"], 9))).contiguous().to(DEV)
     out = {}
-    for tag, env in (("tape", {}), ("tape+dw", {"NOCF_DUO_DW": "1"}), ("tile+record", {"NOCF_DUO_BWD": "0"}), ("recompute", {"NOCF_ACT_REC": "0"})):
+    for tag, env in (("tape", {}), ("tape+dw", {"NOCF_DUO_DW": "1"}), ("tape, sums afterwards", {"NOCF_DUO_CSUM": "0"}), ("tape+dw, sums afterwards", {"NOCF_DUO_DW": "1", "NOCF_DUO_CSUM": "0"}),
+                     ("tile+record", {"NOCF_DUO_BWD": "0"}), ("recompute", {"NOCF_ACT_REC": "0"})):
         monkeypatch.delenv("NOCF_DUO_BWD", raising=False)
         monkeypatch.delenv("NOCF_ACT_REC", raising=False)
         monkeypatch.delenv("NOCF_DUO_DW", raising=False)
+        monkeypatch.delenv("NOCF_DUO_CSUM", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         net = make_net(g, DEV).train()
@@ -548,7 +551,7 @@ def test_tape_adjoint_three_ways_with_all_cost_terms(n, nt, stepper, training, m
         assert _kernel() == ("rollout_duo_bwd_kernel" if tag.startswith("tape") else "rollout_bwd_kernel")
         out[tag] = (float(Jc.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()}, xx.grad.detach().clone())
     ref = out["recompute"]
-    for tag in ("tape", "tape+dw", "tile+record"):
+    for tag in ("tape", "tape+dw", "tape, sums afterwards", "tape+dw, sums afterwards", "tile+record"):
         got = out[tag]
         assert got[0] == ref[0]
         for k in ref[1]:
