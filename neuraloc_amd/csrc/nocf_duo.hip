@@ -246,6 +246,9 @@ __device__ __forceinline__ void mfma_v(f32x4& acc, float w, float b) {
 // Cache policy of the training traffic (aux of the raw buffer builtins: 2 = nt): the activation record (2.7 GB per recording forward at n = 1024), the
 // adjoint's row streams (3.4 GB) and its tape loads (2.7 GB, each read once) are non-temporal -- they pass through the L2 the exchange lives in
 // instead of displacing it.  Measured (round 5, -D...=0 against =2): recording forward 5.66 -> 5.52 ms, adjoint 6.50 -> 6.40 ms.
+#ifndef DU_XST_AUX
+#define DU_XST_AUX 0               // the exchange's stores between groups of one XCD (experiments: 2 = nt, 1 = sc0)
+#endif
 #ifndef DU_STREAM_AUX
 #define DU_STREAM_AUX 2            // the adjoint's row-stream stores
 #endif
@@ -333,7 +336,7 @@ __device__ __forceinline__ u32x4 du_ld(const DCtx& g, int vbyte, int sbyte) {
 __device__ __forceinline__ void du_st(const DCtx& g, int vbyte, int sbyte, f32x4 v) {
     u32x4 u;
     u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
-    if (g.fast) __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 0 /*stays in the XCD's L2*/);
+    if (g.fast) __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, DU_XST_AUX /*stays in the XCD's L2*/);
     else __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 16 /*sc1: write-through*/);
     DU_STORE_GUARD(u);
 }

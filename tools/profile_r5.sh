@@ -40,8 +40,8 @@ PY
 for n in 1024 2048 4096; do timeout 300 python tools/time_width.py 256 $n 2>&1 | grep "^m="; done > $O/18_width256_times.txt
 # 4. timelines (diagnostic build), training times, shock sweep
 for c in "16 128" "16 256" "8 512" "8 1024"; do set -- $c; NOCF_DUO_G=$1 NOCF_LIB_PATH=neuraloc_amd/csrc/libnocf_stamps.so timeout 300 python tools/duo_timeline.py $2 2>&1 | grep -v amdgpu.ids | sed "1s/^/NOCF_DUO_G=$1: /"; done > $O/06_duo_timeline.txt
-timeout 300 python tools/time_train.py 2>&1 | grep "^{" > $O/08_train_times.txt
-timeout 300 python tools/time_train.py singlequad 2>&1 | grep "^{" >> $O/08_train_times.txt
+timeout 300 python tools/time_train.py swarm50 30 2>&1 | grep "^{" > $O/08_train_times.txt
+timeout 300 python tools/time_train.py singlequad 50 2>&1 | grep "^{" >> $O/08_train_times.txt
 for w in singlequad-shock; do timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1; done > $O/17_shock_sweep.json
 for n in 512 4096; do timeout 300 python bench.py --workload singlequad-shock --n $n --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1; done >> $O/17_shock_sweep.json
 bash tools/wr_pmc.sh 128 1024 > /dev/null 2>&1; cp gpurun_out/wr_pmc/summary.txt $O/07_memory_side_writes_by_batch.txt
