@@ -262,19 +262,25 @@ def quick_measure(name, dev, steps=10, warmup=3, n_rows=0):
         for _ in range(warmup):
             na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", meta["alph"])
         torch.cuda.synchronize()
-        L.nocf_profile_begin()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", meta["alph"])
-        torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / steps
-        kms, nl = C.c_double(0.0), C.c_int32(0)
-        L.nocf_profile_end(C.byref(kms), C.byref(nl))
-    kernel_ms = kms.value / max(1, nl.value)
+        # three rounds of `steps` calls, the MEDIAN round is reported (a secondary line: one host hiccup in a 10-call round of a 0.1 ... 1 ms
+        # workload is a 5x error -- seen once in round 5; the headline keeps the contract's single timed region of exactly K steps)
+        rounds = []
+        for _ in range(3):
+            L.nocf_profile_begin()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", meta["alph"])
+            torch.cuda.synchronize()
+            el_r = (time.perf_counter() - t0) / steps
+            kms, nl = C.c_double(0.0), C.c_int32(0)
+            L.nocf_profile_end(C.byref(kms), C.byref(nl))
+            rounds.append((el_r, kms.value / max(1, nl.value)))
+        rounds.sort()
+        el, kernel_ms = rounds[1]
     achieved = flops_per_state_step(meta) * n * nt / (kernel_ms * 1e-3) / 1e12
     return {"workload": f"{name} d={meta['d']} m={meta['m']} nt={nt} n={n}", "traj_per_s": n / el, "ms_per_step": 1e3 * el,
             "kernel": L.nocf_last_rollout_kernel().decode(), "kernel_ms": kernel_ms,
-            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of": "fp32 MFMA / vector peak 157.3 TFLOP/s (the small networks are latency-bound VALU work: SURVEY 8d)"}
+            "protocol": f"median of 3 rounds of {steps} calls", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of": "fp32 MFMA / vector peak 157.3 TFLOP/s (the small networks are latency-bound VALU work: SURVEY 8d)"}
 
 
 def train_measure(name, dev, reps=10):
