@@ -301,13 +301,14 @@ def _bind(L):
                                                [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)] + \
                                                [C.c_void_p, C.c_size_t, C.c_void_p]
         L.nocf_dw_scratch_floats.restype = C.c_size_t
-        L.nocf_bwd_colsum_floats.restype = C.c_size_t
-        L.nocf_bwd_colsum_floats.argtypes = [C.c_int64]
-        L.nocf_rollout_bwd_tape_sums_f32.restype = C.c_int
-        L.nocf_rollout_bwd_tape_sums_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_int64, C.c_int32, C.c_int32,
-                                                     fp, C.c_double] + [C.c_void_p] * 10 + \
-                                                    [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)] + \
-                                                    [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        if hasattr(L, "nocf_bwd_colsum_floats"):                  # (a per-shape library cached by an older build has no such entry: train.py then streams the dw rows)
+            L.nocf_bwd_colsum_floats.restype = C.c_size_t
+            L.nocf_bwd_colsum_floats.argtypes = [C.c_int64]
+            L.nocf_rollout_bwd_tape_sums_f32.restype = C.c_int
+            L.nocf_rollout_bwd_tape_sums_f32.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb), C.c_int64, C.c_int32, C.c_int32,
+                                                         fp, C.c_double] + [C.c_void_p] * 10 + \
+                                                        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)] + \
+                                                        [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.nocf_poison_if_failed_f32.restype = C.c_int
         L.nocf_poison_if_failed_f32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     for name in ("nocf_phi_grad_f32", "nocf_phi_forward_f32"):

@@ -311,7 +311,7 @@ class _OCflowTrain(torch.autograd.Function):
         lib = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
         # the column sums (dw rows, qbar, obar -> dw, db1, db0) come from the kernel's epilogues: no Wb stream, no pass over Qb / Ob for the biases
         # (NOCF_DUO_CSUM=0: the dw rows are streamed and all three are summed afterwards, as up to round 4)
-        csum_on = os.environ.get("NOCF_DUO_CSUM", "1") != "0"
+        csum_on = os.environ.get("NOCF_DUO_CSUM", "1") != "0" and hasattr(lib, "nocf_rollout_bwd_tape_sums_f32")
         Wb = None if csum_on else torch.empty(R, m, device=dev)
         cs = torch.empty(int(lib.nocf_bwd_colsum_floats(n)), device=dev) if csum_on else None
         # NOCF_DUO_DW=1: the two large weight gradients are accumulated in the kernel (weight-gradient roles, nocf_duo_bwd.inc); measured
