@@ -1684,6 +1684,7 @@ int duo_bwd_launch(const NocfPhi* phi, const DevProb& pb, const DuoBwdHost& h, f
         ba.stamps = h.stamps;
         ba.dK1p = dw ? h.dw_scratch : nullptr;
         ba.dK0p = dw ? h.dw_scratch + (size_t)2 * 16 * 512 * 512 : nullptr;
+        if (h.csum && (size_t)(gbase + dp.ngroups) * 3 * 512 > h.csum_floats) return 1;       // (cannot happen with duo_bwd_colsum_floats(n) floats: checked, not assumed)
         ba.csum = h.csum ? h.csum + (size_t)gbase * 3 * 512 : nullptr;
         gbase += dp.ngroups;
         DuoRun rr{r0, h.n};
