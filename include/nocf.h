@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NOCF_VERSION 111            /* major*100 + minor */
+#define NOCF_VERSION 112            /* major*100 + minor */
 
 #define NOCF_E_NULL      (-1)       /* required pointer is NULL                     */
 #define NOCF_E_SHAPE     (-2)       /* d/m/nTh/n/nt out of the supported range      */
@@ -188,6 +188,10 @@ int nocf_rollout_segments_f32(const NocfPhi* phi, const NocfProb* prob, const fl
                               int32_t nseg, int64_t rows_per_seg, const double* t0s, double t1, const int32_t* nts, const int32_t* slot0s,
                               int32_t stepper, const float* alph, float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* 1 when nocf_rollout_segments_f32 has a kernel for this network / problem (host-side, nothing is launched), 0 otherwise: lets a caller
+ * decide before it allocates and fills the segments' buffers (neuraloc_amd/shock.py). */
+int nocf_segments_supported(const NocfPhi* phi, const NocfProb* prob);
 
 /*
  * The last lines of OCflow (src/OCflow.py:80-90): out[0..6] = cost_sums[0..6] / cost_sums[7] (the batch means

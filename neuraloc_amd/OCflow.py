@@ -103,13 +103,15 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates, means=None):
                                           _lib.ptr(zFull), _lib.ptr(ctrlFull),
                                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         else:
-            if means is not None:
-                means.fill_(float("nan"))                   # (a per-shape library built before this entry point existed: the caller checks)
             rc = L.nocf_rollout_f32(C.byref(phi_st), C.byref(prob_st), _lib.ptr(x), n,
                                     float(tspan[0]), float(tspan[1]), int(nt), _STEPPERS[stepper], alph_c,
                                     None, _lib.ptr(persample), _lib.ptr(sums),
                                     _lib.ptr(zFull), _lib.ptr(ctrlFull),
                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            if means is not None and rc == 0:
+                # a per-shape library cached before nocf_rollout_means_f32 existed: the library that RAN fills `means` with its own
+                # nocf_cost_means_f32 (every build has it), so the caller never sees an unwritten buffer
+                rc = L.nocf_cost_means_f32(_lib.ptr(sums), alph_c, _lib.ptr(means), _lib.stream_ptr(dev))
     _lib.check(rc, "nocf_rollout_f32")
     _lib.track_rollout_status(L, dev, "OCflow")
     if _lib.duo_guard(L, "OCflow"):
@@ -118,6 +120,18 @@ def _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates, means=None):
 
 
 MAX_SEGMENTS = 16
+
+
+def segments_supported(x, Phi, prob):
+    """whether nocf_rollout_segments_f32 has a kernel for this network / problem (host-side query: nothing is launched or allocated)"""
+    phi_st, keep1, ws = Phi._c_struct(x.shape[0])
+    prob_st, keep2 = prob._c_struct(x.device)
+    L = _lib.lib_for(Phi.d, Phi.m, Phi.nTh, phi_st.r, prob_st.n_agents, fwd=prob_st.kind != _lib.PROB_QUADCOPTER)
+    if not hasattr(L, "nocf_rollout_segments_f32"):
+        return False
+    if not hasattr(L, "nocf_segments_supported"):               # (a per-shape library cached by an older build: the launch itself answers)
+        return True
+    return bool(L.nocf_segments_supported(C.byref(phi_st), C.byref(prob_st)))
 
 
 def _launch_segments(x, Phi, prob, t0s, t1, nts, rows_per_seg, stepper, alph, slot0s=None, zFull=None, ctrlFull=None):
@@ -213,10 +227,8 @@ def OCflow(x, Phi, prob, tspan, nt, stepper="rk4", alph=[1.0, 1.0, 1.0, 1.0, 1.0
     means = torch.empty(8, dtype=torch.float32, device=x.device) if want_means else None
     if means is not None:
         persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, False, means)
-        # (the means came with the launch that reduced the per-sample table: no separate nocf_cost_means_f32 launch)
-        if hasattr(_lib.lib(), "nocf_rollout_means_f32"):
-            return means[7], [means[i] for i in range(7)]
-        return costs_from_sums(sums, alph)
+        # (the means came with the launch that reduced the per-sample table -- _launch fills them whichever library ran)
+        return means[7], [means[i] for i in range(7)]
     persample, sums, zF, cF = _launch(x, Phi, prob, tspan, nt, stepper, alph, intermediates and not noMean)
     if noMean or intermediates:
         # results that are consumed on the host (plots, files): a timed-out exchange must raise HERE, not at the next call

@@ -181,8 +181,8 @@ def lib_for(d, m, nTh, r, n_agents, fwd=False):
     mode = _jit_mode()
     if mode == "0" or key in _BUILTIN_SHAPES or "NOCF_LIB_PATH" in os.environ:
         return lib()
-    if fwd and key[2] == 2 and 128 < key[1] <= 512 and os.environ.get("NOCF_DUO", "1") not in ("0",):
-        return lib()
+    if fwd and key[2] == 2 and 128 < key[1] <= 512 and os.environ.get("NOCF_DUO", "1") not in ("0",) and not _duo_fallback["on"]:
+        return lib()                              # (after duo_guard's in-process fallback the per-shape per-tile build serves the forward again)
     L = _jit_libs.get(key)
     if L is not None:
         watch_env(L)
@@ -248,6 +248,9 @@ def _bind(L):
                                                 C.c_int32, C.c_int64, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, fp,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_size_t, C.c_void_p]
+    if hasattr(L, "nocf_segments_supported"):
+        L.nocf_segments_supported.restype = C.c_int
+        L.nocf_segments_supported.argtypes = [C.POINTER(NocfPhi), C.POINTER(NocfProb)]
     L.nocf_small_grad_floats.restype = C.c_int64
     L.nocf_small_grad_floats.argtypes = [C.c_int32, C.c_int32]
     L.nocf_rollout_bwd_small_f32.restype = C.c_int

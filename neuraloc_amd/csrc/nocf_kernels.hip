@@ -1890,6 +1890,16 @@ int nocf_ctrl_dim(const NocfProb* prob, int32_t d) {
     return prob->kind == NOCF_PROB_QUADCOPTER ? 4 * prob->n_agents : d;
 }
 
+int nocf_segments_supported(const NocfPhi* phi, const NocfProb* prob) {
+    if (check_phi(phi) || !prob) return 0;
+    DevProb pb;
+    if (fill_prob(prob, phi->d, &pb)) return 0;
+    DevPlan pl;
+    if (make_plan(phi->d, phi->m, phi->nTh, phi->r, pb.nAgents, &pl)) return 0;
+    MonoPlan mpl;
+    return env_int("NOCF_MONO", 1) != 0 && make_mono_plan(pl, pb.nAgents, &mpl) == 0 ? 1 : 0;
+}
+
 static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
                         double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
                         float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
@@ -1929,6 +1939,11 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
     hipError_t e;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const unsigned* errp = nullptr;
+    if (seg) {                                    // segments run on the one-CU kernel only: decided before anything is enqueued or reset
+        MonoPlan probe;
+        if (env_int("NOCF_MONO", 1) == 0 || make_mono_plan(pl, pb.nAgents, &probe) != 0 || workspace_bytes < mono_ws_bytes(probe))
+            return NOCF_E_SHAPE;
+    }
     g_last_errp = nullptr;
     // small networks: one wave per sample, everything in registers (nocf_lane.inc); needs no packed images
     const bool lane_ok = env_int("NOCF_LANE", 1) != 0 && phi->nTh == 2 && phi->m <= 32 && phi->d + 1 <= 32 &&

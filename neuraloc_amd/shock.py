@@ -129,7 +129,7 @@ def _sweep_shared(x, Phi, prob, nt, on_grid, shocks, T, N, tspan, alph, stepper,
     pairs = [(i, t, ns, k) for (i, t, ns) in on_grid for k in range(K)]
     grp = None if group is True else group
     with torch.no_grad():
-        ok = n % 16 == 0
+        ok = n % 16 == 0 and _oc.segments_supported(x, Phi, prob)     # asked BEFORE the unshocked rollout and the pairs' buffers exist
         raw = []
         if ok:
             # (1) the unshocked trajectory, once
@@ -139,9 +139,13 @@ def _sweep_shared(x, Phi, prob, nt, on_grid, shocks, T, N, tspan, alph, stepper,
             for c0 in range(0, len(pairs), _oc.MAX_SEGMENTS):
                 chunk = pairs[c0:c0 + _oc.MAX_SEGMENTS]
                 P = len(chunk)
-                xs = torch.stack([zF[ns, :, :d] + shocks[k:k + 1] for (_, _, ns, k) in chunk]).reshape(P * n, d).contiguous()
-                Z = torch.empty(nt + 3, P * n, d + 4, dtype=x.dtype, device=x.device)
-                Cc = torch.empty(nt + 3, P * n, cdim, dtype=x.dtype, device=x.device)
+                try:
+                    xs = torch.stack([zF[ns, :, :d] + shocks[k:k + 1] for (_, _, ns, k) in chunk]).reshape(P * n, d).contiguous()
+                    Z = torch.empty(nt + 3, P * n, d + 4, dtype=x.dtype, device=x.device)
+                    Cc = torch.empty(nt + 3, P * n, cdim, dtype=x.dtype, device=x.device)
+                except torch.OutOfMemoryError:                  # the pair-at-a-time path needs one pair's buffers only
+                    ok = False
+                    break
                 # every pair's copy of the unshocked prefix (slots beyond its nShock are overwritten by its second segment)
                 Z[:N + 1].view(N + 1, P, n, d + 4).copy_(zF.unsqueeze(1).expand(N + 1, P, n, d + 4))
                 Cc[:N + 1].view(N + 1, P, n, cdim).copy_(cF.unsqueeze(1).expand(N + 1, P, n, cdim))

@@ -157,6 +157,7 @@ class _OCflowTrain(torch.autograd.Function):
                 _lib.check(rc, "nocf_rollout_tape_f32")
                 if recorded.value:
                     ctx.tape = tape
+                    ctx.tape_lib = L                              # the adjoint must read this tape with the library that wrote it
                 else:                                             # another kernel ran (residency, a knob): no tape -- the forward is
                     tape = None                                   # repeated below WITH the activation record that kernel can write
         if tape is not None:
@@ -308,7 +309,7 @@ class _OCflowTrain(torch.autograd.Function):
         lam0 = torch.empty(n, d, device=dev) if ctx.x_needs_grad else None
         Y, Ab, Qb, Ob = (torch.empty(R, m, device=dev) for _ in range(4))
         Gb = torch.empty(R, D1, device=dev)
-        lib = _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents)
+        lib = getattr(ctx, "tape_lib", None) or _lib.lib_for(net.d, net.m, net.nTh, phi_st.r, prob_st.n_agents, fwd=True)
         # the column sums (dw rows, qbar, obar -> dw, db1, db0) come from the kernel's epilogues: no Wb stream, no pass over Qb / Ob for the biases
         # (NOCF_DUO_CSUM=0: the dw rows are streamed and all three are summed afterwards, as up to round 4)
         csum_on = os.environ.get("NOCF_DUO_CSUM", "1") != "0" and hasattr(lib, "nocf_rollout_bwd_tape_sums_f32")
