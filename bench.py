@@ -87,13 +87,12 @@ def flops_per_state_step(meta):
 
 
 def cpu_baseline(meta, sd, xtarget, x, nt, budget_s=60.0):
-    """The oracle (checker / CPU port of the reference) timed on the host cores of this box, SURVEY 8(d) protocol on a
-    BOUNDED sample: the same batch, the first few of the nt RK4 steps at the same step size h (every step costs the same
-    ~1 850 eager ops, so trajectories/s of the full rollout = n / (t_sample * nt / steps)).  Legs: 1 intra-op thread, all host
-    cores, and the best of a thread-count probe (eager PyTorch on ~460 small ops per RHS evaluation does not scale to every
-    core of a big host: at 256 threads it is slower than at 1).  Each leg: 3 warm-up steps, median of 3 timed calls, the number
-    of steps per call sized to ~1/6 of the time budget; a thread count whose single step already takes longer than 8 s is
-    reported from that one step.  The headline value is the best leg."""
+    """The oracle (checker / CPU port of the reference) timed on the host cores of this box: FULL nt-step rollouts of the same batch
+    (SURVEY 8(d) times whole OCflow calls).  Protocol: (1) a thread-count probe -- the second of two 1-step calls per count (eager PyTorch
+    on ~460 small ops per RHS evaluation does not scale to every core of a big host: at 256 threads it is slower than at 1); (2) at the
+    best probed count: one 2-step warm-up call, then the MEDIAN OF 3 FULL ROLLOUTS = `value` (fewer when one rollout alone would exceed a
+    third of the time budget: the count is stated).  Nothing is extrapolated into `value`; the 1-thread / all-cores figures of the probe are
+    labelled as probe figures."""
     from oracle import ocflow_oracle as orc
     kind = {"Cross2D": orc.KIND_CROSS2D, "SwarmTraj": orc.KIND_SWARM, "Quadcopter": orc.KIND_QUAD}[meta["prob_class"]]
     P = orc.PhiParams.from_state_dict(sd)
@@ -117,45 +116,24 @@ def cpu_baseline(meta, sd, xtarget, x, nt, budget_s=60.0):
                 notes.append(f"{th} threads: one step took {step_s[th]:.1f} s, larger counts not probed")
                 break
         best = min(step_s, key=step_s.get)
-        legs = {}
-        for th in sorted({1, best, ncpu}):
-            if th not in step_s:                         # (all cores, beyond the point where the probe stopped)
-                legs[th] = (step_s[max(step_s)], 1, "not run: slower than the last probed count; that count's step time stands in")
-                continue
-            if step_s[th] > 8.0:
-                legs[th] = (step_s[th], 1, "one step, one call")
-                continue
-            steps = int(max(1, min(8, (budget_s / 6.0) / (3.0 * step_s[th]))))
-            for _ in range(3):
-                call(th, 1)                              # >= 3 warm-ups
-            legs[th] = (float(np.median([call(th, steps) for _ in range(3)])) / steps, steps, "3 warm-ups, median of 3 calls")
-    traj = {th: n / (v[0] * nt) for th, v in legs.items()}
-    head = max(traj, key=traj.get)
-    table = ", ".join(f"{k}t:{n / nt / v:.0f}" for k, v in step_s.items())
-    legtxt = "; ".join(f"{th} thread(s): {v[1]} step(s)/call, {v[2]}" for th, v in legs.items())
-    # ... and ONE full nt-step rollout at the headline thread count validates the extrapolation inside this run (SURVEY 8(d) times full
-    # rollouts): skipped only when it would take longer than the remaining budget allows
-    full_s, value, basis = None, traj[head], "extrapolated from the sampled steps"
-    est_full = legs[head][0] * nt
-    if est_full <= max(10.0, budget_s / 2.0):
-        torch.set_num_threads(head)
-        with torch.no_grad():
+        est_full = step_s[best] * nt
+        reps = 3 if est_full <= budget_s / 3.0 else 1
+        call(best, 2)                                    # warm-up at the chosen count
+        fulls = []
+        for _ in range(reps):
+            torch.set_num_threads(best)
             t0 = time.perf_counter()
             orc.rollout(x, P, S, [0.0, 1.0], nt, "rk4", meta["alph"])
-            full_s = time.perf_counter() - t0
-        if abs(full_s - est_full) > 0.10 * est_full:     # disagreement: the measured full rollout is the figure
-            value, basis = n / full_s, "one full rollout (the sampled-step extrapolation was off by more than 10 %)"
-    return {"value": value, "unit": "trajectories/s", "cores": head, "kind": "port", "value_basis": basis,
-            "extrapolated_traj_per_s": traj[head], "full_rollout_s": full_s, "full_rollout_traj_per_s": (n / full_s) if full_s else None,
-            "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
-            "one_thread": traj[1], "all_cores": traj[ncpu], "all_cores_count": ncpu, "best_probe": traj[best], "best_probe_threads": best,
-            "sample": f"PROTOCOL: not SURVEY 8(d)'s >= 20 full calls (a full rollout takes seconds on this host) but, per leg, 3 warm-up steps and the "
-                      f"median of 3 calls of <= 8 RK4 steps, scaled to {nt} steps -- validated in this run by ONE full {nt}-step rollout at the headline "
-                      f"thread count (full_rollout_s; beyond 10 % disagreement the measured rollout becomes `value`).  n={n} rows, the first steps of "
-                      f"the {nt}-step RK4 rollout at the same h; {legtxt}; "
-                      f"thread probe (1 step, traj/s-equivalent): {table}" + ("; " + "; ".join(notes) if notes else "")
-                      + f"; eager PyTorch {torch.__version__}",
-            "seconds_per_step": legs[head][0]}
+            fulls.append(time.perf_counter() - t0)
+    full_s = float(np.median(fulls))
+    table = ", ".join(f"{k}t:{n / nt / v:.0f}" for k, v in step_s.items())
+    return {"value": n / full_s, "unit": "trajectories/s", "cores": best, "kind": "port",
+            "value_basis": f"median of {reps} full {nt}-step rollout(s) at the best probed thread count",
+            "full_rollout_s": full_s, "full_rollouts_s": fulls, "cpu_model": _cpu_model(), "os_cpu_count": ncpu,
+            "probe_one_thread": n / nt / step_s[1], "probe_all_cores": (n / nt / step_s[ncpu]) if ncpu in step_s else None, "all_cores_count": ncpu,
+            "sample": f"n={n} rows, the whole {nt}-step RK4 rollout (the workload of `value`), {reps} time(s) at {best} intra-op threads, median; "
+                      f"thread probe (second of two 1-step calls, traj/s-equivalent -- probe figures, not `value`): {table}"
+                      + ("; " + "; ".join(notes) if notes else "") + f"; eager PyTorch {torch.__version__}"}
 
 
 def _cpu_model():
@@ -321,6 +299,9 @@ def train_measure(name, dev, reps=10):
     # the two rollout kernels' own times: separate iterations (reading a profile window synchronises, which would sit inside the wall time)
     fwd_ms = bwd_ms = 0.0
     kreps = 3
+    from neuraloc_amd import train as _train
+    _train.VENDOR_GEMM["events"].clear()
+    _train.VENDOR_GEMM["on"] = True
     for _ in range(kreps):
         opt.zero_grad()
         (Jc, _), ms, fk = window(lambda: na.OCflow(x, net, prob, [0.0, 1.0], nt, "rk4", alph))
@@ -329,11 +310,18 @@ def train_measure(name, dev, reps=10):
         bwd_ms += ms
         opt.step()
     torch.cuda.synchronize()
+    _train.VENDOR_GEMM["on"] = False
+    vendor_ms = sum(e0.elapsed_time(e1) for e0, e1 in _train.VENDOR_GEMM["events"]) / kreps
+    _train.VENDOR_GEMM["events"].clear()
     na.check_errors(sync=True)
     fl = 3.0 * flops_per_state_step(meta) * n * nt
     return {"workload": f"train {name} d={meta['d']} m={meta['m']} nt={nt} n={n} (Adam step, prob.train())", "train_iter_ms": 1e3 * el,
             "trained_traj_per_s": n / el, "forward_kernel": fk, "forward_kernel_ms": fwd_ms / kreps,
             "adjoint_kernel": bk, "adjoint_kernel_ms": bwd_ms / kreps, "flops_per_iteration": fl,
+            "vendor_gemm_ms": vendor_ms,
+            "vendor_gemm_note": "weight-gradient contractions X'Y over the adjoint's row streams that run as hipBLASLt GEMMs (torch.bmm + fixed-order slab "
+                                "sum, neuraloc_amd/train.py:_contract); 0 = every gradient was accumulated inside the hand-written adjoint. Kept for "
+                                "swarm50: the library runs them at ~0.9 of the fp32 MFMA roof, the in-kernel alternative (NOCF_DUO_DW=1) is slower",
             "frac": fl / el / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "frac_of": "3 x SURVEY 8(d) forward FLOPs per iteration over the WHOLE iteration's wall time, of the fp32 MFMA peak", "Jc": float(Jc.detach())}
 

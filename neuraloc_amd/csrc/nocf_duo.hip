@@ -258,6 +258,9 @@ __device__ __forceinline__ void mfma_v(f32x4& acc, float w, float b) {
 #ifndef DU_REC_AUX
 #define DU_REC_AUX 2               // the activation record's stores
 #endif
+#ifndef DU_SLOWNAP
+#define DU_SLOWNAP 8               // 64-clock quanta between failed polls when a group has several tiles (du_spin)
+#endif
 #define DU_PIN(v) asm volatile("" : "+s"(v))
 
 struct DCtx {
@@ -336,9 +339,18 @@ __device__ __forceinline__ u32x4 du_ld(const DCtx& g, int vbyte, int sbyte) {
 __device__ __forceinline__ void du_st(const DCtx& g, int vbyte, int sbyte, f32x4 v) {
     u32x4 u;
     u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
+    // (round 6: the guard sits in the write-through branch only -- the branch where tools/store_hazard_check.py finds overwritten store data
+    // without it, 24 places: the U store followed by the tanh's v_rcp.  A guard behind EVERY store pinned the stores between the written-out MFMAs
+    // and cost 0.5 %; build() runs the checker over the ISA of every build and refuses a library with a finding)
     if (g.fast) __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, DU_XST_AUX /*stays in the XCD's L2*/);
-    else __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 16 /*sc1: write-through*/);
-    DU_STORE_GUARD(u);
+    else {
+        // (two wait states directly behind the store, fenced against the scheduler on both sides: an asm that merely NAMES the data as an input
+        // lets the compiler rebuild a constant payload -- the sentinel -- in registers that overlap the store's, in between)
+        __builtin_amdgcn_raw_buffer_store_b128(u, g.xrs, vbyte, sbyte, 16 /*sc1: write-through*/);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 __device__ __forceinline__ void du_st_sent(const DCtx& g, int vbyte, int sbyte) {
     const f32x4 sv = {__uint_as_float(DU_SENT), __uint_as_float(DU_SENT), __uint_as_float(DU_SENT), __uint_as_float(DU_SENT)};
@@ -356,7 +368,7 @@ __device__ __forceinline__ bool du_spin(DCtx& g, int& spins, unsigned what) {
     if (g.dead) return true;
     // (with one tile per group an evaluation is one dependent chain and a short nap finds the data sooner; with two the other tile's
     // work covers the wait and fewer polls leave more of L2 to it: 5.03 -> 4.97 ms at n = 1024, 2.85 -> 2.83 at n = 256)
-    if (g.slow) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
+    if (g.slow) __builtin_amdgcn_s_sleep(DU_SLOWNAP); else __builtin_amdgcn_s_sleep(1);
     ++spins;
     if ((spins & 63) == 0) {
         const unsigned ev = __builtin_amdgcn_readfirstlane(__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -380,13 +392,10 @@ __device__ __forceinline__ void du_gather(DCtx& g, int wave, int lane, int sbyte
     while (true) {
 #pragma unroll
         for (int u = 0; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) v[u] = du_ld(g, lane * 16, sbyte + (wave + 4 * u) * 1024);
-        // (a failed poll looks at ONE fragment: 4 vector instructions instead of 4 per fragment in the way of the co-resident role's MFMAs)
-        bool bad = du_bad(v[0]);
-        if (!__any(bad)) {
+        bool bad = false;
 #pragma unroll
-            for (int u = 1; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) bad |= du_bad(v[u]);
-            if (!__any(bad)) break;
-        }
+        for (int u = 0; u < NFW; ++u) if (NF % 4 == 0 || wave + 4 * u < NF) bad |= du_bad(v[u]);
+        if (!__any(bad)) break;
         if (du_spin(g, spins, what)) break;
     }
     du_wait_end(g, tw, lane);
@@ -406,12 +415,10 @@ __device__ __forceinline__ void du_gather2(DCtx& g, int which, int lane, int sby
     while (true) {
 #pragma unroll
         for (int u = 0; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) v[u] = du_ld(g, lane * 16, sbyte + (which + 2 * u) * 1024);
-        bool bad = du_bad(v[0]);
-        if (!__any(bad)) {
+        bool bad = false;
 #pragma unroll
-            for (int u = 1; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) bad |= du_bad(v[u]);
-            if (!__any(bad)) break;
-        }
+        for (int u = 0; u < NFW; ++u) if (NF % 2 == 0 || which + 2 * u < NF) bad |= du_bad(v[u]);
+        if (!__any(bad)) break;
         if (du_spin(g, spins, what)) break;
     }
     du_wait_end(g, tw, lane);
@@ -574,9 +581,9 @@ struct DuoRun { long row0, n_total; };             // rows of this launch inside
 
 // REC: the training variant also stores every stage input (RollArgs::sAll); ZF: intermediates (trajectories and controls, one more
 // evaluation per step); the plain evaluation variant carries no trace of either
-// ONE: the launch has one tile per group in the default geometry (257 ... 512 rows): the instantiation WITH the owner's flag below.  The flag
+// MODE 1 (ONE): the launch has one tile per group in the default geometry (257 ... 512 rows): the instantiation WITH the owner's flag below.  The flag
 // costs that geometry registers it does not have (11 spilled instead of 2-5: n = 1024 +2 %), and only one-tile groups gain from it
-template <int PD, bool REC, bool ZF, int GM = DU_G, int KBMT = DU_KBM, bool ONE = false>
+template <int PD, bool REC, bool ZF, int GM = DU_G, int KBMT = DU_KBM, int MODE = 0>
 __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __restrict__ dpp, DevProb pb, float* ws, RollArgs ra, DuoRun rr) {
     typedef DuoCfg<GM, KBMT> CF;
     constexpr int G = CF::G, MTM = CF::MTM, KS = CF::KS, SPM = CF::SPM, KBW = CF::KBW, KB1 = CF::KB1, WPG = CF::WPG, HPM = CF::HPM;
@@ -652,6 +659,11 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ft = KS > 1 ? wave % MTM : wave, kh = KS > 1 ? wave / MTM : 0;                 // this wave's feature tile of the member, its part of the contraction
     int NT = dp.NT; DU_PIN(NT);                                 // (ONE: still read at run time -- as a compile-time 1 the kernel came out with 31 spilled registers instead of 11)
+    // MODE (default geometry, m = 512): 0 = several tiles per group: neither the owner's flag nor predictive waiting is compiled in (both only
+    // ever ran with one tile per group; their state -- DCtx, the anchors, the calibration -- cost the multi-tile launches 1.1 %, round 6);
+    // 1 = 32 one-tile groups (every CU holds the two roles of one member): flag + prediction; 2 = other one-tile launches: prediction only
+    constexpr bool ONE = MODE == 1;
+    constexpr bool PRED = MODE != 0 || GM != DU_G;
     constexpr bool FLAGS = ONE || GM != DU_G;                   // the local owner's "about to publish" flag for the stage-state gatherers (see own_state)
     const int d = dp.d;
     const float hN = dp.hN;
@@ -749,7 +761,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         if (tid < DU_DP) lds[DA_CW + tid] = ws[dp.oCW + tid];
         if (tid < 192 && (tid & 63) < HPM) lds[DA_VEC + tid] = ws[dp.oVec + (tid >> 6) * MW + member * HPM + (tid & 63)];
         for (int i = tid; i < SPM * NT * DS_STRIDE; i += 256) lds[DAT + i] = 0.f;
-        du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DAPW, wave, lane);     // (one tile per group: measured, see DCtx; dbg bit 16 forces it on)
+        if (PRED) du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DAPW, wave, lane);     // (one tile per group: measured, see DCtx; dbg bit 16 forces it on)
         __syncthreads();
         for (int i = tid; i < SPM * NT * DU_DP; i += 256) {
             const int s = i / DU_DP, c = i - s * DU_DP;
@@ -783,7 +795,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // (issued in front of the previous tile's P2, one L2 round trip off the critical path); it is used if it shows no sentinel.
         auto gather_g = [&](int s, int parG, bool have, u32x4 (&pv)[G]) -> f32x4 {
             int spins = 0;
-            const DWait tw = du_wait_begin(g, DPW_G, s / SPM);
+            const DWait tw = du_wait_begin(g, PRED ? DPW_G : -1, s / SPM);
             while (true) {
                 if (!have) g_request(s, parG, pv);
                 have = false;
@@ -892,7 +904,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         };
         // ... cost part (off the critical path: it runs behind P1, while the u0 exchange travels): sum p^2, dPhi/dt, the x-only terms
         // from role B -> the four cost integrals of evaluation e-1
-        auto own_costs = [&](int s, int e, float hs, int pst, int pk) {
+        // (pre: qa_ / qb_ hold the answer of a request issued just before -- DU_X_SWAP -- instead of the one that rode with the partial gradients)
+        auto own_costs = [&](int s, int e, float hs, int pst, int pk, bool pre = false, unsigned qa_ = 0u, unsigned qb_ = 0u) {
             const int t = s / SPM, j = s % SPM;
             const int parG = (e - 1) & 1;
             const bool rk_last = (pst == nstage - 1);
@@ -900,7 +913,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
             const int sbase = DAT + s * DS_STRIDE;
             const float4 oc = L4[(sbase + DS_OC) >> 2];
             const float sp2 = oc.x, gt = oc.y;
-            unsigned qa = __float_as_uint(oc.z), qb = __float_as_uint(oc.w);
+            unsigned qa = pre ? qa_ : __float_as_uint(oc.z), qb = pre ? qb_ : __float_as_uint(oc.w);
             bool have = true;
             // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
             float q_ = 0.f, w_ = 0.f;
@@ -1126,7 +1139,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         DTL(40 * t + 17);
 #endif
                         if (KS == 1 || kh == 0) du_st(g, vb, xV + ((par * NT + t) * KBM + MTM * member + ft) * 1024, v);
-                        du_anchor(g, t, lane);                  // (predictive waiting: this wave's next waits for tile t count from here)
+                        if (PRED) du_anchor(g, t, lane);        // (predictive waiting: this wave's next waits for tile t count from here)
                         DTL(40 * t + 12);
                         if (REC && ra.act && (!fin || ra.tapeSc) && (KS == 1 || kh == 0))      // activation record: tanh(q)
                             rec_store(rec_block(2, e - 1), rec_off(t), tq[0], tq[1], tq[2], tq[3]);
@@ -1155,8 +1168,16 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // gather these two delayed it: they take as long as the u0 hop.  The waves that own nothing of this tile go on: with two
                     // tiles they are the next tile's owners.)
                     if (sown >= 0) {
-                        if (e > 1 && p_st != nstage) own_costs(sown, e, p_hs, p_st, p_k);
+                        // z / A^T z FIRST (round 6): it is vector work, and the SIMD's ALU is free while v travels (role B polls for it); the cost
+                        // part is mostly the wait for role B's cost scalars, requested here so that the round trip runs under that work
+                        const bool oc = e > 1 && p_st != nstage;
+                        unsigned pqa = DU_SENT, pqb = DU_SENT;
+                        if (oc) {
+                            const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((e - 1) % 3) * NT + sown / SPM) * G + member) * (2 * SPM) + 2 * (sown % SPM)) * 4, 16);
+                            pqa = v2[0]; pqb = v2[1];
+                        }
                         azc_step(sown, fin);
+                        if (oc) own_costs(sown, e, p_hs, p_st, p_k, true, pqa, pqb);
                     }
                     DTL(40 * t + 9);
                 }
@@ -1224,7 +1245,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // =====================================================================================================
         for (int i = tid; i < DU_KBD * MTM * 64; i += 256) L4[(DB_K4 >> 2) + i] = ws4[dp.oK4 + (long)member * DU_KBD * MTM * 64 + i];
         if (tid < HPM) lds[DB_VEC + tid] = ws[dp.oVec + 2 * MW + member * HPM + tid];
-        du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DBPW, wave, lane);
+        if (PRED) du_calibrate(g, ((dp.dbg & 8) || (NT > 1 && !(dp.dbg & 16))) ? -1 : DBPW, wave, lane);
         __syncthreads();
         const DXPar xp = du_x_params(pb, PD);
         const int nsub = nstage + (ZF ? 1 : 0);
@@ -1296,7 +1317,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 // ================= P3: a = w + hN K1[:,H_c]^T v ; y = tanh(o) . a =================
                 const int fo = ((par * NT + t) * KBM + MTM * member + ft) * 1024;
                 DTL(40 * t + 24);
-                du_gather<KBM>(g, wave, lane, xV + ((par * NT + t) * KBM) * 1024, DB_VF >> 2, DUK_V, DPW_V, t);
+                du_gather<KBM>(g, wave, lane, xV + ((par * NT + t) * KBM) * 1024, DB_VF >> 2, DUK_V, PRED ? DPW_V : -1, t);
                 __syncthreads();
                 DTL(40 * t + 25);
                 u32x4 thv = {DU_SENT, DU_SENT, DU_SENT, DU_SENT};
@@ -1326,10 +1347,8 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     if (KS == 1) thv = du_ld(g, vb, xT + fo);
                 };
                 f32x4 acc = du_gemm_lds<KBW, true>(W, (DB_VF >> 2) + kh * KBW * 64 + lane, mid);
-                // (the first look at the tanh(o) answer stays BEHIND the product: left to itself the scheduler hoists the sentinel test into
-                // the MFMA stream, two k-blocks behind the request, behind an s_waitcnt vmcnt(0) that also waits for the three resets'
-                // acknowledgements)
-                asm volatile("" : "+v"(thv));
+                // (round 4 pinned the first look at the tanh(o) answer behind the product with an empty asm; measured again in round 6 on one box,
+                // the pin costs 1.6 % at n = 1024 and gains nothing at 128 ... 512 rows: taken out)
                 DTL(40 * t + 26);
                 {
                     int spins = 0;
@@ -1451,7 +1470,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     }
                 }
                 }
-                du_anchor(g, t, lane);
+                if (PRED) du_anchor(g, t, lane);
                 if (dp.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 DTL(40 * t + 29);
             }
@@ -1528,12 +1547,12 @@ int duo_workspace_bytes(int d, int m, int nTh, int r, int n_agents, long n, size
     return 0;
 }
 
-template <int PD, bool REC, bool ZF, int GM, int KBMT = DU_KBM, bool ONE = false>
-static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF, GM, KBMT, ONE>); }
-template <int GM, bool ONE = false>
+template <int PD, bool REC, bool ZF, int GM, int KBMT = DU_KBM, int MODE = 0>
+static const void* duo_fn() { return reinterpret_cast<const void*>(rollout_duo_kernel<PD, REC, ZF, GM, KBMT, MODE>); }
+template <int GM, int MODE = 0>
 static const void* duo_pick(bool c2, bool rec, bool zf) {
-    return c2 ? (rec ? duo_fn<2, true, false, GM, DU_KBM, ONE>() : (zf ? duo_fn<2, false, true, GM, DU_KBM, ONE>() : duo_fn<2, false, false, GM, DU_KBM, ONE>()))
-              : (rec ? duo_fn<3, true, false, GM, DU_KBM, ONE>() : (zf ? duo_fn<3, false, true, GM, DU_KBM, ONE>() : duo_fn<3, false, false, GM, DU_KBM, ONE>()));
+    return c2 ? (rec ? duo_fn<2, true, false, GM, DU_KBM, MODE>() : (zf ? duo_fn<2, false, true, GM, DU_KBM, MODE>() : duo_fn<2, false, false, GM, DU_KBM, MODE>()))
+              : (rec ? duo_fn<3, true, false, GM, DU_KBM, MODE>() : (zf ? duo_fn<3, false, true, GM, DU_KBM, MODE>() : duo_fn<3, false, false, GM, DU_KBM, MODE>()));
 }
 
 // Which form for a launch of n rows?  NOCF_DUO_G = 8 / 16 forces one; otherwise the fine form where the batch has at most 16 tiles, i.e.
@@ -1566,9 +1585,13 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
     // (the ONE instantiation: one launch of 32 one-tile groups in the default geometry, i.e. every CU holds the two roles of one member -- the
     // case the flag is for; measured, tools/r5_ab.sh: 512 rows 3.33 -> 3.13 ms, but 300 / 384 rows (19 / 24 groups, no census pairing) 3.40 -> 3.49)
     const bool one = GM == DU_G && dp0.NT == 1 && dp0.ngroups == 32 && ra_in.n <= chunk;
+    // (MODE 0 has no predictive-waiting code: it serves every launch sequence in which some launch has several tiles per group -- a single
+    // launch of <= 2048 rows always has NT of its first chunk; a chunked call's LAST chunk may have one tile per group and then simply polls)
+    const int mode = GM != DU_G ? 0 : (dp0.NT > 1 ? 0 : (one ? 1 : 2));
     const void* fk = narrow ? (c2 ? (rec ? duo_fn<2, true, false, 4, 16>() : (zf ? duo_fn<2, false, true, 4, 16>() : duo_fn<2, false, false, 4, 16>()))
                                   : (rec ? duo_fn<3, true, false, 4, 16>() : (zf ? duo_fn<3, false, true, 4, 16>() : duo_fn<3, false, false, 4, 16>())))
-                            : (GM == DU_G ? (one ? duo_pick<DU_G, true>(c2, rec, zf) : duo_pick<DU_G>(c2, rec, zf)) : duo_pick<DU_GMAX>(c2, rec, zf));
+                            : (GM == DU_G ? (mode == 1 ? duo_pick<DU_G, 1>(c2, rec, zf) : (mode == 2 ? duo_pick<DU_G, 2>(c2, rec, zf) : duo_pick<DU_G, 0>(c2, rec, zf)))
+                                          : duo_pick<DU_GMAX>(c2, rec, zf));
     const int wpg = 2 * GM;
     // residency: all 16 x ngroups workgroups spin on each other, so every one of them must be resident at once: two per CU
     // (256 registers per lane, <= 80 KB LDS).  The grid is checked against what the runtime says fits; the stream must be

@@ -28,6 +28,20 @@ def _step_sizes(tspan, nt):
 
 
 _SCRATCH = {}
+# measurement hook (bench.py): with "on" set, every weight-gradient contraction that runs as a LIBRARY GEMM (torch.bmm / matmul = hipBLASLt) is
+# bracketed by events, so that the bench line can say how much of an iteration a vendor library computes (`vendor_gemm_ms`)
+VENDOR_GEMM = {"on": False, "events": []}
+
+
+def _vendor(fn):
+    if not VENDOR_GEMM["on"]:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    VENDOR_GEMM["events"].append((e0, e1))
+    return r
 
 
 def _contract(X, Y, out=None):
@@ -42,10 +56,10 @@ def _contract(X, Y, out=None):
     K = X.shape[0]
     S = next((s_ for s_ in (256, 128, 64, 32, 16, 8, 4, 2) if K % s_ == 0 and K // s_ >= 2048 and s_ * m * n <= (1 << 25)), 1)
     if S > 1 and X.is_contiguous() and Y.is_contiguous():
-        r = torch.bmm(X.view(S, K // S, m).transpose(1, 2), Y.view(S, K // S, n)).sum(0)
+        r = _vendor(lambda: torch.bmm(X.view(S, K // S, m).transpose(1, 2), Y.view(S, K // S, n)).sum(0))
         return r if out is None else out.add_(r)
     if m > 512 or n > 512 or m * n > 128 * 160 or X.dtype != torch.float32:
-        r = X.t() @ Y
+        r = _vendor(lambda: X.t() @ Y)
         return r if out is None else out.add_(r)
     dev = X.device
     sc = _SCRATCH.get(dev)

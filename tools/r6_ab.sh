@@ -2,7 +2,7 @@
 # A/B of whole trees on ONE lease, interleaved: bash tools/r6_ab.sh OUT tree1 tree2 ...   (each tree: a checkout with its own built
 # neuraloc_amd/csrc/libnocf.so and bench.py; "." = HEAD).  Headline bench only (no CPU leg, no other workloads), REPS rounds.
 # Round 6: ab/r3 (c01c1a4), ab/r4 (2704cb1) and HEAD -> profiles/r6/01_ab_r3_vs_head.txt
-out=$1; shift
+out=$(realpath -m "$1"); shift
 export NOCF_JIT=0
 root=$PWD
 : > "$out"
