@@ -476,6 +476,18 @@ __device__ __forceinline__ unsigned long long du_now() {
     return t;
 }
 #define DTL(id) do { if (tlp) { const unsigned long long t_ = du_now(); if (lane == 0) tlp[id] = t_; } } while (0)
+#elif defined(NOCF_ACC)
+// Second diagnostic build (-DNOCF_ACC, tools/duo_acc.py): the same points as LAP counters -- the shader clocks since the wave's previous point are
+// added to the point's bucket (32 per wave, in LDS), over the WHOLE rollout, and written out at the end: where every wave's time goes (waits for
+// each exchange kind, barriers, products, epilogues), for every wave of the launch.  ~40 clocks per point (MI355X_MICROARCH.md).
+__device__ __forceinline__ unsigned long long du_acc_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define DTL(id) do { const unsigned long long n_ = du_acc_now(); \
+                     if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(lds) + acc_base_ + ((id) % 40), (unsigned)(n_ - acc_t_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                     acc_t_ = n_; } while (0)
 #else
 #define DTL(id) do { } while (0)
 #endif
@@ -681,6 +693,15 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     const float4* ws4 = reinterpret_cast<const float4*>(ws);
     float4* L4 = reinterpret_cast<float4*>(lds);
     const int vb = lane * 16;                                   // this lane's 16 bytes of a fragment
+#ifdef NOCF_ACC
+    const int acc_base_ = dp.ldsFloats - 256 + wave * 32;       // (the host reserves 256 more floats in this build)
+    if (lane < 32) lds[acc_base_ + lane] = 0.f;
+    unsigned long long acc_t_ = du_acc_now();
+    auto acc_dump = [&]() {
+        DTL(31);
+        if (ra.stamps && lane < 32) ra.stamps[((((long)group * 16 + member) * 2 + role) * 4 + wave) * 32 + lane] = reinterpret_cast<const unsigned*>(lds)[acc_base_ + lane];
+    };
+#endif
 #ifdef NOCF_STAMPS
     unsigned long long* tlp = nullptr;
     const int e_probe = (ra.nt / 2) * ((ra.stepper == NOCF_RK4) ? 4 : 1) + 2;
@@ -1239,6 +1260,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         ra.z_out[row * (d + 4) + i] = (i < d) ? lds[sbase + DS_Z0 + i] : lds[sbase + DS_CZ + (i - d)];
             }
         }
+#ifdef NOCF_ACC
+        acc_dump();
+#endif
     } else {
         // =====================================================================================================
         // role B: x-only cost terms, P3, P4
@@ -1475,9 +1499,16 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 DTL(40 * t + 29);
             }
         }
+#ifdef NOCF_ACC
+        acc_dump();
+#endif
     }
 }
 
+#ifdef NOCF_ACC
+#undef DTL
+#define DTL(id) do { } while (0)                   // (the lap counters exist in the forward only)
+#endif
 #include "nocf_duo_bwd.inc"
 
 // ------------------------------------------------------------------------------------------
@@ -1510,6 +1541,9 @@ static int make_duo_plan(int d, int m_real, int nTh, int r, int n_agents, long n
     // (adjoint: + the column-sum cells of the epilogues, 2 x 64 floats behind role A's carve and 64 behind role B's)
     const int ldsA = bwd ? DAB_T + 2 * dp.NT * DSB_STRIDE + 128 : DA_T + fine + 4 * DPW_WORDS + (16 / G) * dp.NT * DS_STRIDE, ldsB = DB_END + (bwd ? 64 : 4 * DPW_WORDS);
     dp.ldsFloats = std::max(std::max(ldsA, ldsB), dw ? DC_END : 0);
+#ifdef NOCF_ACC
+    if (!bwd) dp.ldsFloats += 256;                                                 // (the lap counters of the diagnostic build)
+#endif
     if ((size_t)dp.ldsFloats * 4 > 80 * 1024) return NOCF_E_LDS;                // two workgroups per CU
     long o = 0;                                                                    // floats
     dp.oPlan = o; o += 256;

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of library builds of HEAD's sources on one lease: bash tools/r6_variants.sh OUT "ROWS..." libA.so libB.so ...
+# a library may carry environment knobs: libX.so:NOCF_DUO_UDELAY=3:NOCF_DUO_DBG=8
 # (libraries in neuraloc_amd/csrc/, built from nocf_duo.hip with -D... experiment macros; evaluation forward, kernel time from HIP events)
 out=$(realpath -m "$1"); rows=$2; shift 2
 export NOCF_JIT=0
@@ -7,7 +8,8 @@ export NOCF_JIT=0
 for rep in $(seq 1 ${REPS:-2}); do
   for l in "$@"; do
     for n in $rows; do
-      line=$(NOCF_LIB_PATH=$PWD/neuraloc_amd/csrc/$l python bench.py --n $n --steps ${STEPS:-50} --warmup 5 --no-cpu-baseline --no-other-workloads 2>/dev/null | grep '^{' | tail -1)
+      lib=${l%%:*}; envs=""; [ "$lib" != "$l" ] && envs=$(echo "${l#*:}" | tr ':' ' ')
+      line=$(env $envs NOCF_LIB_PATH=$PWD/neuraloc_amd/csrc/$lib python bench.py --n $n --steps ${STEPS:-50} --warmup 5 --no-cpu-baseline --no-other-workloads 2>/dev/null | grep '^{' | tail -1)
       python - "$rep" "$l" "$n" "$line" >> "$out" <<'PY'
 import json, sys
 rep, l, n, line = sys.argv[1:5]
