@@ -9,7 +9,10 @@
  *   - every pointer marked "device" is a HIP device pointer on the current device;
  *     all tensors are dense row-major fp32 unless stated otherwise
  *   - functions enqueue work on `stream` (a hipStream_t passed as void*, 0 = default
- *     stream) and return without synchronising; nothing is allocated or freed
+ *     stream) and return without synchronising; nothing is allocated or freed -- with ONE opt-in exception since version 113: with
+ *     NOCF_LANE_ONE=1 in the environment the first rollout of a small network (m <= 32: one wavefront per sample) on a device allocates
+ *     256 bytes of device memory for the life of the process: the self-resetting ticket words (one per stream, at most 64) with which that
+ *     kernel's last workgroup forms the cost sums itself instead of a second launch (measured slower on the MI355X: off by default)
  *   - return value: 0 ok; <0 argument error (NOCF_E_*); >0 a hipError_t
  *   - no exceptions, no aborts.  Process-global state: the diagnostic environment knobs (NOCF_LANE, NOCF_FIXED, NOCF_DUO,
  *     NOCF_MONO, NOCF_DEBUG ...) are read from the environment once, at first use, and cached (nocf_debug_reload_env drops the
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NOCF_VERSION 112            /* major*100 + minor */
+#define NOCF_VERSION 113            /* major*100 + minor */
 
 #define NOCF_E_NULL      (-1)       /* required pointer is NULL                     */
 #define NOCF_E_SHAPE     (-2)       /* d/m/nTh/n/nt out of the supported range      */

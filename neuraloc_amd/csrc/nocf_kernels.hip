@@ -1363,9 +1363,9 @@ __global__ void __launch_bounds__(512) prob_kernel(DevPlan pl, DevProb pb, const
 // (means != null: also the 7 means and Jc of cost_means_kernel, same arithmetic on the same rounded sums -- one launch less per call when no
 // all-reduce stands between the sums and the means)
 struct MeanArgs { float* means; float a0, a3, a4, a5; };
-__global__ void __launch_bounds__(256) cost_sum_kernel(float* __restrict__ tab, long n, float* __restrict__ out,
-                                                       const unsigned* __restrict__ err, MeanArgs ma = MeanArgs{nullptr, 0.f, 0.f, 0.f, 0.f}) {
-    __shared__ double sh[256 * 7];
+// (the body is shared with the lane kernel's last-workgroup reduction, nocf_lane.inc: same arithmetic, same order -> the same bits)
+__device__ __forceinline__ void cost_sum_body(double* sh /* [256 * 7] LDS */, float* __restrict__ tab, long n, float* __restrict__ out,
+                                              const unsigned* __restrict__ err, const MeanArgs& ma) {
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (long row = threadIdx.x; row < n; row += 256)
         for (int j = 0; j < 7; ++j) acc[j] += (double)tab[row * 7 + j];
@@ -1391,6 +1391,11 @@ __global__ void __launch_bounds__(256) cost_sum_kernel(float* __restrict__ tab, 
         }
     }
     if (failed) for (long i = threadIdx.x; i < n * 7; i += 256) tab[i] = __int_as_float(0x7fc00000);
+}
+__global__ void __launch_bounds__(256) cost_sum_kernel(float* __restrict__ tab, long n, float* __restrict__ out,
+                                                       const unsigned* __restrict__ err, MeanArgs ma = MeanArgs{nullptr, 0.f, 0.f, 0.f, 0.f}) {
+    __shared__ double sh[256 * 7];
+    cost_sum_body(sh, tab, n, out, err, ma);
 }
 
 // means of the 7 cost terms and Jc from the 8 sums, one launch instead of a dozen tiny elementwise ones
@@ -1900,6 +1905,34 @@ int nocf_segments_supported(const NocfPhi* phi, const NocfProb* prob) {
     return env_int("NOCF_MONO", 1) != 0 && make_mono_plan(pl, pb.nAgents, &mpl) == 0 ? 1 : 0;
 }
 
+// Ticket words of the one-launch small rollouts (nocf_lane.inc: the last workgroup to finish reduces the per-sample table).  256 B per device,
+// allocated and zeroed once; a word is self-resetting (atomicInc wraps at the grid size), and every (device, stream) pair gets its own word --
+// launches on one stream are ordered, launches on different streams never share a word.  More than 64 streams: the two-launch path.
+static unsigned* lane_ticket(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<int, unsigned*> base;
+    static std::map<std::pair<int, hipStream_t>, int> slot;
+    static std::map<int, int> used;
+    int dev = 0;
+    if (hipGetDevice(&dev)) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base.count(dev)) {
+        unsigned* p = nullptr;
+        if (hipMalloc((void**)&p, 64 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); base[dev] = nullptr; }
+        else if (hipMemset(p, 0, 64 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); base[dev] = nullptr; }
+        else base[dev] = p;
+    }
+    unsigned* b = base[dev];
+    if (!b) return nullptr;
+    const auto key = std::make_pair(dev, st);
+    auto it = slot.find(key);
+    if (it == slot.end()) {
+        if (used[dev] >= 64) return nullptr;
+        it = slot.emplace(key, used[dev]++).first;
+    }
+    return b + it->second;
+}
+
 static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x, int64_t n,
                         double t0, double t1, int32_t nt, int32_t stepper, const float* alph,
                         float* z_out, float* persample, float* cost_sums, float* zFull, float* ctrlFull,
@@ -1952,6 +1985,12 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         LaneArgs la;
         la.P = DevPhi{phi->K0, phi->b0, phi->K, phi->b, phi->w, phi->A, phi->cw, phi->cb_dev};
         la.d = phi->d; la.m = phi->m; la.r = phi->r; la.nAg = pb.nAgents; la.cb = phi->cb;
+        // one launch per call (round 6, NOCF_LANE_ONE=1): with a ticket word the kernel's last workgroup forms the sums (and means) itself.
+        // OFF by default -- measured on the MI355X (profiles/r6/07_lane_one_launch.txt): the agent-scope release every workgroup needs in front of
+        // its ticket is an L2 write-back (buffer_wbl2 sc1), 256-512 of them cost 7-15 us, more than the 4-us kernel and launch gap they replace
+        unsigned* ticket = (cost_sums && env_int("NOCF_LANE_ONE", 0) != 0) ? lane_ticket(st) : nullptr;
+        la.sums = ticket ? cost_sums : nullptr; la.ticket = ticket;
+        la.means = mean_args.means; la.a0 = mean_args.a0; la.a3 = mean_args.a3; la.a4 = mean_args.a4; la.a5 = mean_args.a5;
         const int grid = (int)((n + 3) / 4);
         const int MPsel = phi->m <= 16 ? 16 : 32;
         const int DPsel = phi->d + 1 <= 8 ? 8 : (phi->d + 1 <= 16 ? 16 : 32);
@@ -1968,7 +2007,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         if (e) return (int)e;
         g_last_kernel = "rollout_lane_kernel";
         if (g_prof_on) { (void)hipEventRecord(ev1, st); g_prof_events.emplace_back(ev0, ev1); }
-        if (cost_sums) {
+        if (cost_sums && !ticket) {
             hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, st, persample, (long)n, cost_sums, errp, mean_args);
             e = hipGetLastError();
             if (e) return (int)e;

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(L):
             "nocf_version", "nocf_workspace_bytes", "nocf_ctrl_dim", "nocf_selftest_mfma"} <= names
     for n in names:
         assert hasattr(L, n), f"{n} declared in nocf.h but not exported"
-    assert L.nocf_version() == 112
+    assert L.nocf_version() == 113
     # ... and every export of the library that the Python layer binds is declared (a C caller sees the same surface)
     bound = set(re.findall(r"\bL\.(nocf_[a-z0-9_]+)\b", open(os.path.join(REPO, "neuraloc_amd", "_lib.py")).read()))
     assert bound <= names, f"bound but not declared in nocf.h: {sorted(bound - names)}"
