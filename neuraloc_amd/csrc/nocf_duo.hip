@@ -764,7 +764,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         u32x4 u;
         u.x = __float_as_uint(a); u.y = __float_as_uint(b); u.z = __float_as_uint(c); u.w = __float_as_uint(d_);
         __builtin_amdgcn_raw_buffer_store_b128(u, rs, off, 0, DU_REC_AUX);
+#ifndef DU_R_NOGUARD
         DU_STORE_GUARD(u);
+#endif
     };
 
     if (role == 0) {
