@@ -477,6 +477,7 @@ __device__ __forceinline__ unsigned long long du_now() {
 }
 #define DTL(id) do { if (tlp) { const unsigned long long t_ = du_now(); if (lane == 0) tlp[id] = t_; } } while (0)
 #elif defined(NOCF_ACC)
+#define DTLB(id) DTL(id)                            /* (points that exist in the lap-counter build only: in front of the gathers' barriers) */
 // Second diagnostic build (-DNOCF_ACC, tools/duo_acc.py): the same points as LAP counters -- the shader clocks since the wave's previous point are
 // added to the point's bucket (32 per wave, in LDS), over the WHOLE rollout, and written out at the end: where every wave's time goes (waits for
 // each exchange kind, barriers, products, epilogues), for every wave of the launch.  ~40 clocks per point (MI355X_MICROARCH.md).
@@ -490,6 +491,9 @@ __device__ __forceinline__ unsigned long long du_acc_now() {
                      acc_t_ = n_; } while (0)
 #else
 #define DTL(id) do { } while (0)
+#endif
+#ifndef DTLB
+#define DTLB(id) do { } while (0)
 #endif
 
 // ---- x-only running-cost terms (Cross2D.py:89-160, SwarmTraj.py:89-162): cyclic pairing, agent a meets (a+j) mod N
@@ -1080,6 +1084,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                         else if (SPM == 4) du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);      // (every wave is an owner)
                         else { const int wh = ((wave - (t & 3)) & 3) - 1; if (wh >= 0 && wh < 2) { wait_owner(); du_gather2<DU_KBD>(g, wh, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S); } }
                     } else du_gather<DU_KBD>(g, wave, lane, xS + ((par * NT + t) * DU_KBD) * 1024, DA_SF >> 2, DUK_S);
+                    DTLB(40 * t + 13);
                     __syncthreads();
                     DTL(40 * t + 5);
                     {
@@ -1126,6 +1131,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     // store: a poll issued at once reaches L2 before the slowest member's fragment and costs a whole second round trip)
                     for (int i = 0; i < g.udelay; ++i) __builtin_amdgcn_s_sleep(1);
                     du_gather<KBM>(g, wave, lane, xU + ((par * NT + t) * KBM) * 1024, DA_UF >> 2, DUK_U);
+                    DTLB(40 * t + 14);
                     __syncthreads();
                     DTL(40 * t + 10);
                     {
@@ -1344,6 +1350,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 const int fo = ((par * NT + t) * KBM + MTM * member + ft) * 1024;
                 DTL(40 * t + 24);
                 du_gather<KBM>(g, wave, lane, xV + ((par * NT + t) * KBM) * 1024, DB_VF >> 2, DUK_V, PRED ? DPW_V : -1, t);
+                DTLB(40 * t + 15);
                 __syncthreads();
                 DTL(40 * t + 25);
                 u32x4 thv = {DU_SENT, DU_SENT, DU_SENT, DU_SENT};

@@ -19,11 +19,11 @@ import neuraloc_amd as na                      # noqa: E402
 from neuraloc_amd import _lib                  # noqa: E402
 
 A_PT = {0: "own: entry (from the previous point of this wave)", 1: "own: WAIT for the partial gradients", 2: "own: sum, RK update, S stored", 3: "own: cost part (incl. wait for role B's scalars)",
-        4: "to the S gather", 5: "S gather: polls + staging + barrier", 6: "P1 product", 7: "P1 epilogue + U / TH stores",
-        8: "to the U gather", 9: "owner: z / A^T z (+ cost part) done", 10: "U gather: nap + polls + staging + barrier", 11: "P2 product",
+        4: "to the S gather", 13: "S gather: polls + staging (the two gatherer waves)", 5: "S gather: the workgroup barrier behind it", 6: "P1 product", 7: "P1 epilogue + U / TH stores",
+        8: "to the U gather", 9: "owner: z / A^T z (+ cost part) done", 14: "U gather: nap + polls + staging", 10: "U gather: the barrier behind it", 11: "P2 product",
         12: "P2 epilogue: ack wait, tanh, V store", 31: "tail (terminal costs, outputs)"}
 B_PT = {20: "tile entry (from the previous point)", 21: "own states: polls + scatter + barrier", 22: "pair sums + barrier", 23: "QW combine + store",
-        24: "to the V gather", 25: "V gather: polls + staging + barrier", 26: "P3 product (resets, tanh(o) request inside)", 27: "tanh(o) wait, y written",
+        24: "to the V gather", 15: "V gather: polls + staging", 25: "V gather: the barrier behind it", 26: "P3 product (resets, tanh(o) request inside)", 27: "tanh(o) wait, y written",
         28: "y barrier (+ P4 operand reads)", 29: "P4 products + G stores", 31: "tail"}
 
 

@@ -5,7 +5,7 @@
 out=$(realpath -m "$1"); shift
 export NOCF_JIT=0
 root=$PWD
-: > "$out"
+mkdir -p "$(dirname "$out")"; : > "$out"
 for rep in $(seq 1 ${REPS:-3}); do
   for t in "$@"; do
     cd "$root/$t"

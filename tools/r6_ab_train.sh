@@ -3,7 +3,7 @@
 # iteration from the library's HIP events, then the wall time of an Adam iteration)
 out=$(realpath -m "$1"); shift
 export NOCF_JIT=0
-: > "$out"
+mkdir -p "$(dirname "$out")"; : > "$out"
 for rep in $(seq 1 ${REPS:-2}); do
   for l in "$@"; do
     a=$(NOCF_LIB_PATH=$PWD/neuraloc_amd/csrc/$l python tools/time_rec.py 2>&1 | tail -1)

@@ -4,7 +4,7 @@
 # (libraries in neuraloc_amd/csrc/, built from nocf_duo.hip with -D... experiment macros; evaluation forward, kernel time from HIP events)
 out=$(realpath -m "$1"); rows=$2; shift 2
 export NOCF_JIT=0
-: > "$out"
+mkdir -p "$(dirname "$out")"; : > "$out"
 for rep in $(seq 1 ${REPS:-2}); do
   for l in "$@"; do
     for n in $rows; do
