@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     // 1 = 32 one-tile groups (every CU holds the two roles of one member): flag + prediction; 2 = other one-tile launches: prediction only
     constexpr bool ONE = MODE == 1;
     constexpr bool PRED = MODE != 0 || GM != DU_G;
+    constexpr bool OSPLIT = GM == DU_GMAX;                      // the owner's step in two parts (own_state_split / own_book): the fine geometry only, measured
     constexpr bool FLAGS = ONE || GM != DU_G;                   // the local owner's "about to publish" flag for the stage-state gatherers (see own_state)
     const int d = dp.d;
     const float hN = dp.hN;
@@ -929,18 +930,119 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                 if (lane == 0) L4[(sbase + DS_OC) >> 2] = make_float4(sp2, gt, __uint_as_float(qa), __uint_as_float(qb));
             }
         };
+        // (round 6) The owner's step in TWO parts, for the FINE geometry (one tile per group, one own sample per member: OSPLIT).  On the path partial
+        // gradients -> stage state only what the stage state needs: the fixed-order sum, K = h (-g), x = base + cx K (base = the step's start state
+        // or its RK accumulator: one LDS read at a wave-uniform offset) and the store.  The accumulator, the state at the step's end, the trajectory /
+        // record rows and sum p^2 are done by own_book behind P2 from the gradient parked in the sample's A^T z slot (dead between this sum and the
+        // next azc_step).  Same expressions on the same operands: the same bits.  Measured on one lease (profiles/r6/05_variants_tried.txt, o1):
+        // 256 rows 2.62 -> 2.54 ms, 128 rows 2.31 -> 2.30; in the default geometry it LOSES (two tiles per group: +12 %; 512 rows: +2 %) -- there the
+        // owner waves' work behind P2 holds the next tile's stage-state gather back -- so that geometry keeps the one-part step.
+        auto own_state_split = [&](int s, int e, float hs, int pst, int pk, float t_pub, u32x4 (&pv)[G]) {
+            const int t = s / SPM, j = s % SPM;
+            const int parG = (e - 1) & 1, parS = e & 1;
+            const bool rk_last = (pst == nstage - 1);
+            const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
+            const float rk_wx = (pst < 2) ? 0.5f : 1.f;
+            const int sbase = DAT + s * DS_STRIDE;
+            const bool pctrl = (pst == nstage);
+            const bool xFromA = !pctrl && rk_last && nstage != 1;
+            const float cx = pctrl ? 0.f : (rk_last ? rk_wa : rk_wx);
+            DTL(40 * t + 0);
+            const float4 b4 = L4[(sbase + (xFromA ? DS_ZA : DS_Z0) + pi) >> 2];                            // (in flight while the partials are polled)
+            g_request(s, parG, pv);
+            const f32x4 gs = gather_g(s, parG, true, pv);
+            if (FLAGS && lane == 0) __hip_atomic_store(reinterpret_cast<int*>(lds) + DAFL + t, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            DTL(40 * t + 1);
+            if (pact) {
+                const float xb[4] = {b4.x, b4.y, b4.z, b4.w};
+                f32x4 xs;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int i = pi + e4;
+                    const float K = hs * -gs[e4];
+                    const float x_ = pctrl ? xb[e4] : xb[e4] + cx * K;
+                    xs[e4] = (i < d) ? x_ : (i == d ? t_pub : 0.f);
+                }
+                const int lp = (psl * 16 + SPM * member + j) * 16 + pmt * 1024;
+                du_st(g, lp, xS + ((parS * NT + t) * DU_KBD) * 1024, xs);
+                du_st_sent(g, lp, xS + (((parS ^ 1) * NT + t) * DU_KBD) * 1024);
+                L4[(sbase + DS_XS + pi) >> 2] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+                L4[(sbase + DS_AZC + pi) >> 2] = make_float4(gs[0], gs[1], gs[2], gs[3]);                   // parked for own_book
+            }
+            DTL(40 * t + 2);
+        };
+        // ... the rest of that step, behind P2: leaves sum p^2 (sp2) and dPhi/dt (gt) of the evaluation just answered for the cost part
+        auto own_book = [&](int s, int e, float hs, int pst, int pk, float& sp2, float& gt) {
+            const int t = s / SPM, j = s % SPM;
+            const bool rk_last = (pst == nstage - 1);
+            const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
+            const float rk_wx = (pst < 2) ? 0.5f : 1.f;
+            const int sbase = DAT + s * DS_STRIDE;
+            const bool pctrl = (pst == nstage);
+            const bool xFromA = !pctrl && rk_last && nstage != 1;
+            const bool accum = !pctrl && !rk_last;
+            const float cx = pctrl ? 0.f : (rk_last ? rk_wa : rk_wx);
+            const float4 z04 = L4[(sbase + DS_Z0 + pi) >> 2], zA4 = L4[(sbase + DS_ZA + pi) >> 2], g4 = L4[(sbase + DS_AZC + pi) >> 2];
+            const f32x4 gs = {g4.x, g4.y, g4.z, g4.w};
+            float q0 = 0.f;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) if (pact && pi + e4 < d) q0 += gs[e4] * gs[e4];
+            const float gdv = pd_e == 0 ? gs[0] : (pd_e == 1 ? gs[1] : (pd_e == 2 ? gs[2] : gs[3]));
+            const long orow = rr.row0 + own_row(t, j);
+            const bool orow_ok = own_row(t, j) < ra.n;
+            if (pact) {
+                const float z0[4] = {z04.x, z04.y, z04.z, z04.w};
+                float zA[4] = {zA4.x, zA4.y, zA4.z, zA4.w}, zn[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int i = pi + e4;
+                    const float K = hs * -gs[e4];
+                    const float xb = xFromA ? zA[e4] : z0[e4];
+                    const float x_ = pctrl ? z0[e4] : xb + cx * K;
+                    const float an = (pst == 0 ? z0[e4] : zA[e4]) + rk_wa * K;
+                    zA[e4] = accum ? an : zA[e4];
+                    zn[e4] = (rk_last && !pctrl) ? x_ : z0[e4];
+                    if (i >= d) { zn[e4] = 0.f; zA[e4] = 0.f; }
+                }
+                if (ZF && orow_ok) {
+                    if (pctrl) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 < d) ra.ctrlFull[((long)(pk + 1) * rr.n_total + orow) * ra.cdim + pi + e4] = -gs[e4];
+                    } else if (rk_last) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) if (pi + e4 < d) ra.zFull[((long)(pk + 1) * rr.n_total + orow) * (d + 4) + pi + e4] = zn[e4];
+                    }
+                }
+                if (!pctrl) {
+                    if (rk_last) L4[(sbase + DS_Z0 + pi) >> 2] = make_float4(zn[0], zn[1], zn[2], zn[3]);
+                    else L4[(sbase + DS_ZA + pi) >> 2] = make_float4(zA[0], zA[1], zA[2], zA[3]);
+                }
+                if (REC && ra.sAll && e <= ra.nt * nstage + (ra.tapeSc ? 1 : 0) && own_row(t, j) < ra.n) {
+                    const float4 x4 = L4[(sbase + DS_XS + pi) >> 2];
+                    rec_row(ra.sAll + (((long)(e - 1)) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 1), pi, x4.x, x4.y, x4.z, x4.w);
+                }
+                if (REC && ra.act && own_row(t, j) < ra.n)
+                    rec_row(ra.act + 4 * ra.actRows * MW + (((long)(e - 2)) * rr.n_total + rr.row0 + own_row(t, j)) * (d + 1), pi, gs[0], gs[1], gs[2], gs[3]);
+            }
+            sp2 = 0.f; gt = 0.f;
+            if (pst != nstage) {
+                sp2 = sum64(q0);
+                gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gdv), pd_lane));
+            }
+        };
         // ... cost part (off the critical path: it runs behind P1, while the u0 exchange travels): sum p^2, dPhi/dt, the x-only terms
         // from role B -> the four cost integrals of evaluation e-1
         // (pre: qa_ / qb_ hold the answer of a request issued just before -- DU_X_SWAP -- instead of the one that rode with the partial gradients)
-        auto own_costs = [&](int s, int e, float hs, int pst, int pk, bool pre = false, unsigned qa_ = 0u, unsigned qb_ = 0u) {
+        auto own_costs = [&](int s, int e, float hs, int pst, int pk, bool pre = false, unsigned qa_ = 0u, unsigned qb_ = 0u, float sp2_ = 0.f, float gt_ = 0.f) {
             const int t = s / SPM, j = s % SPM;
             const int parG = (e - 1) & 1;
             const bool rk_last = (pst == nstage - 1);
             const float rk_wa = (nstage == 1) ? 1.f : ((pst == 0 || pst == 3) ? c16 : c26);
             const int sbase = DAT + s * DS_STRIDE;
-            const float4 oc = L4[(sbase + DS_OC) >> 2];
+            float4 oc = make_float4(sp2_, gt_, 0.f, 0.f);            // (OSPLIT: own_book hands sum p^2 and dPhi/dt over in registers)
+            if (!OSPLIT) oc = L4[(sbase + DS_OC) >> 2];
             const float sp2 = oc.x, gt = oc.y;
-            unsigned qa = pre ? qa_ : __float_as_uint(oc.z), qb = pre ? qb_ : __float_as_uint(oc.w);
+            unsigned qa = (pre || OSPLIT) ? qa_ : __float_as_uint(oc.z), qb = (pre || OSPLIT) ? qb_ : __float_as_uint(oc.w);
             bool have = true;
             // (q, w) of this sample at the state of evaluation e-1, from role B of this member (every lane loads the same 8 bytes)
             float q_ = 0.f, w_ = 0.f;
@@ -1063,7 +1165,7 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                     int sown = -1;                                  // this wave's own sample of the tile, if any: sample s belongs to wave s & 3
 #pragma unroll
                     for (int j = 0; j < SPM; ++j) if (((SPM * t + j) & 3) == wave) sown = SPM * t + j;
-                    if (e > 1 && sown >= 0) own_state(sown, e, p_hs, p_st, p_k, (float)te, false, pf);
+                    if (e > 1 && sown >= 0) { if (OSPLIT) own_state_split(sown, e, p_hs, p_st, p_k, (float)te, pf); else own_state(sown, e, p_hs, p_st, p_k, (float)te, false, pf); }
                     // ================= P1: o = K0[H_c,:] s + b0 ; u0 = sigma(o), tanh(o) =================
                     DTL(40 * t + 4);
                     // (the two waves that own nothing of this tile fetch the stage states: the owners have just stored theirs, and a load issued
@@ -1205,8 +1307,10 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
                             const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(g.xrs, 0, xQ + (((((e - 1) % 3) * NT + sown / SPM) * G + member) * (2 * SPM) + 2 * (sown % SPM)) * 4, 16);
                             pqa = v2[0]; pqb = v2[1];
                         }
+                        float sp2b = 0.f, gtb = 0.f;
+                        if (OSPLIT && e > 1) own_book(sown, e, p_hs, p_st, p_k, sp2b, gtb);      // (reads the parked gradient: before azc_step rewrites its slot)
                         azc_step(sown, fin);
-                        if (oc) own_costs(sown, e, p_hs, p_st, p_k, true, pqa, pqb);
+                        if (oc) own_costs(sown, e, p_hs, p_st, p_k, true, pqa, pqb, sp2b, gtb);
                     }
                     DTL(40 * t + 9);
                 }
