@@ -680,7 +680,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
     // 1 = 32 one-tile groups (every CU holds the two roles of one member): flag + prediction; 2 = other one-tile launches: prediction only
     constexpr bool ONE = MODE == 1;
     constexpr bool PRED = MODE != 0 || GM != DU_G;
-    constexpr bool OSPLIT = GM == DU_GMAX;                      // the owner's step in two parts (own_state_split / own_book): the fine geometry only, measured
+    // the owner's step in two parts (own_state_split / own_book): where a group has ONE tile -- the fine geometry, and the one-tile launches of the
+    // 256-wide geometry (MODE 1 there: n <= 1024) -- measured; with two tiles per group it loses in every geometry
+    constexpr bool OSPLIT = GM == DU_GMAX || (GM == 4 && MODE == 1);
     constexpr bool FLAGS = ONE || GM != DU_G;                   // the local owner's "about to publish" flag for the stage-state gatherers (see own_state)
     const int d = dp.d;
     const float hN = dp.hN;
@@ -935,8 +937,9 @@ __global__ void __launch_bounds__(256, 2) rollout_duo_kernel(const DuoPlan* __re
         // or its RK accumulator: one LDS read at a wave-uniform offset) and the store.  The accumulator, the state at the step's end, the trajectory /
         // record rows and sum p^2 are done by own_book behind P2 from the gradient parked in the sample's A^T z slot (dead between this sum and the
         // next azc_step).  Same expressions on the same operands: the same bits.  Measured on one lease (profiles/r6/05_variants_tried.txt, o1):
-        // 256 rows 2.62 -> 2.54 ms, 128 rows 2.31 -> 2.30; in the default geometry it LOSES (two tiles per group: +12 %; 512 rows: +2 %) -- there the
-        // owner waves' work behind P2 holds the next tile's stage-state gather back -- so that geometry keeps the one-part step.
+        // 256 rows 2.62 -> 2.53 ms, 128 rows 2.31 -> 2.29, a 256-wide network at n = 1024 2.82 -> 2.70; with two tiles per group it LOSES in every
+        // geometry (default: +12 %, 256-wide at n = 2048: +3 %; also 512 rows of the default geometry: +2 %) -- there the owner waves' work behind P2
+        // holds the next tile's stage-state gather back -- so those launches keep the one-part step.
         auto own_state_split = [&](int s, int e, float hs, int pst, int pk, float t_pub, u32x4 (&pv)[G]) {
             const int t = s / SPM, j = s % SPM;
             const int parG = (e - 1) & 1, parS = e & 1;
@@ -1735,8 +1738,11 @@ int duo_launch(const NocfPhi* phi, const DevProb& pb, const RollArgs& ra_in, flo
     // (MODE 0 has no predictive-waiting code: it serves every launch sequence in which some launch has several tiles per group -- a single
     // launch of <= 2048 rows always has NT of its first chunk; a chunked call's LAST chunk may have one tile per group and then simply polls)
     const int mode = GM != DU_G ? 0 : (dp0.NT > 1 ? 0 : (one ? 1 : 2));
-    const void* fk = narrow ? (c2 ? (rec ? duo_fn<2, true, false, 4, 16>() : (zf ? duo_fn<2, false, true, 4, 16>() : duo_fn<2, false, false, 4, 16>()))
-                                  : (rec ? duo_fn<3, true, false, 4, 16>() : (zf ? duo_fn<3, false, true, 4, 16>() : duo_fn<3, false, false, 4, 16>())))
+    const bool n1 = narrow && dp0.NT == 1 && ra_in.n <= chunk;      // 256-wide geometry, one tile per group: the instantiation with the two-part owner's step
+    const void* fk = narrow ? (n1 ? (c2 ? (rec ? duo_fn<2, true, false, 4, 16, 1>() : (zf ? duo_fn<2, false, true, 4, 16, 1>() : duo_fn<2, false, false, 4, 16, 1>()))
+                                        : (rec ? duo_fn<3, true, false, 4, 16, 1>() : (zf ? duo_fn<3, false, true, 4, 16, 1>() : duo_fn<3, false, false, 4, 16, 1>())))
+                                  : (c2 ? (rec ? duo_fn<2, true, false, 4, 16>() : (zf ? duo_fn<2, false, true, 4, 16>() : duo_fn<2, false, false, 4, 16>()))
+                                        : (rec ? duo_fn<3, true, false, 4, 16>() : (zf ? duo_fn<3, false, true, 4, 16>() : duo_fn<3, false, false, 4, 16>()))))
                             : (GM == DU_G ? (mode == 1 ? duo_pick<DU_G, 1>(c2, rec, zf) : (mode == 2 ? duo_pick<DU_G, 2>(c2, rec, zf) : duo_pick<DU_G, 0>(c2, rec, zf)))
                                           : duo_pick<DU_GMAX>(c2, rec, zf));
     const int wpg = 2 * GM;
