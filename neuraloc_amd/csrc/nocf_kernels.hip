@@ -1998,8 +1998,9 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             if (hipEventCreate(&ev0) || hipEventCreate(&ev1)) return (int)hipErrorUnknown;
             (void)hipEventRecord(ev0, st);
         }
-#define NOCF_LANE_LAUNCH(MPV, DPV) do { if (s_all) hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, true>), dim3(grid), dim3(256), 0, st, la, pb, ra); \
-                                         else hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, false>), dim3(grid), dim3(256), 0, st, la, pb, ra); } while (0)
+        const size_t laneLds = ticket ? (size_t)(256 * 7 * 8 + 16) : 0;      // (the last-workgroup reduction's scratch: only with a ticket)
+#define NOCF_LANE_LAUNCH(MPV, DPV) do { if (s_all) hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, true>), dim3(grid), dim3(256), laneLds, st, la, pb, ra); \
+                                         else hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, false>), dim3(grid), dim3(256), laneLds, st, la, pb, ra); } while (0)
         if (MPsel == 16) { if (DPsel == 8) { NOCF_LANE_LAUNCH(16, 8); } else if (DPsel == 16) { NOCF_LANE_LAUNCH(16, 16); } else { NOCF_LANE_LAUNCH(16, 32); } }
         else             { if (DPsel == 8) { NOCF_LANE_LAUNCH(32, 8); } else if (DPsel == 16) { NOCF_LANE_LAUNCH(32, 16); } else { NOCF_LANE_LAUNCH(32, 32); } }
 #undef NOCF_LANE_LAUNCH
