@@ -1988,7 +1988,7 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
         // one launch per call (round 6, NOCF_LANE_ONE=1): with a ticket word the kernel's last workgroup forms the sums (and means) itself.
         // OFF by default -- measured on the MI355X (profiles/r6/07_lane_one_launch.txt): the agent-scope release every workgroup needs in front of
         // its ticket is an L2 write-back (buffer_wbl2 sc1), 256-512 of them cost 7-15 us, more than the 4-us kernel and launch gap they replace
-        unsigned* ticket = (cost_sums && env_int("NOCF_LANE_ONE", 0) != 0) ? lane_ticket(st) : nullptr;
+        unsigned* ticket = (cost_sums && !s_all && env_int("NOCF_LANE_ONE", 0) != 0) ? lane_ticket(st) : nullptr;
         la.sums = ticket ? cost_sums : nullptr; la.ticket = ticket;
         la.means = mean_args.means; la.a0 = mean_args.a0; la.a3 = mean_args.a3; la.a4 = mean_args.a4; la.a5 = mean_args.a5;
         const int grid = (int)((n + 3) / 4);
@@ -1999,8 +1999,9 @@ static int rollout_impl(const NocfPhi* phi, const NocfProb* prob, const float* x
             (void)hipEventRecord(ev0, st);
         }
         const size_t laneLds = ticket ? (size_t)(256 * 7 * 8 + 16) : 0;      // (the last-workgroup reduction's scratch: only with a ticket)
-#define NOCF_LANE_LAUNCH(MPV, DPV) do { if (s_all) hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, true>), dim3(grid), dim3(256), laneLds, st, la, pb, ra); \
-                                         else hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, false>), dim3(grid), dim3(256), laneLds, st, la, pb, ra); } while (0)
+#define NOCF_LANE_LAUNCH(MPV, DPV) do { if (s_all) hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, true>), dim3(grid), dim3(256), 0, st, la, pb, ra); \
+                                         else if (ticket) hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, false, true>), dim3(grid), dim3(256), laneLds, st, la, pb, ra); \
+                                         else hipLaunchKernelGGL((rollout_lane_kernel<MPV, DPV, false>), dim3(grid), dim3(256), 0, st, la, pb, ra); } while (0)
         if (MPsel == 16) { if (DPsel == 8) { NOCF_LANE_LAUNCH(16, 8); } else if (DPsel == 16) { NOCF_LANE_LAUNCH(16, 16); } else { NOCF_LANE_LAUNCH(16, 32); } }
         else             { if (DPsel == 8) { NOCF_LANE_LAUNCH(32, 8); } else if (DPsel == 16) { NOCF_LANE_LAUNCH(32, 16); } else { NOCF_LANE_LAUNCH(32, 32); } }
 #undef NOCF_LANE_LAUNCH
